@@ -1,0 +1,226 @@
+// HBM-bound helper kernels of the hot path (all coalesced 16-byte stores, fp16 NHWC8 blobs).
+//
+// K1 preprocess   : replaces cv2.cvtColor(frame, COLOR_BGR2RGB) (backend/app/routes/camera.py:225)
+//                   + the detector input blob (insightface scrfd: zero canvas, (rgb-127.5)/128)
+// K4 align        : replaces the landmark alignment inside face_recognition.face_encodings
+//                   (camera.py:237, face_service.py:179) with the ArcFace 5-point similarity warp
+// K5 tail l2norm  : unit-normalises the FC output (embedding)
+// gallery upload  : replaces np.array([ENCODINGS[t] ...]) rebuilt per call (face_service.py:409)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frp_internal.h"
+
+namespace frp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------ K1
+// one thread per canvas pixel: 3 u8 in, 16 bytes out.  rgb_in: input already RGB.
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, int B, int H, int W,
+                                                         long row_stride, long frame_stride,
+                                                         _Float16* __restrict__ out, int Hc, int Wc, int rgb_in) {
+    const long total = (long)B * Hc * Wc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wc);
+        const long r = i / Wc;
+        const int y = (int)(r % Hc);
+        const int b = (int)(r / Hc);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;   // letterbox canvas is u8 zero
+        if (y < H && x < W) {
+            const uint8_t* p = src + b * frame_stride + y * row_stride + 3L * x;
+            c0 = (float)p[0]; c1 = (float)p[1]; c2 = (float)p[2];
+        }
+        const float r_ = rgb_in ? c0 : c2, g_ = c1, b_ = rgb_in ? c2 : c0;
+        half8 v;
+        v[0] = (_Float16)((r_ - 127.5f) * (1.0f / 128.0f));
+        v[1] = (_Float16)((g_ - 127.5f) * (1.0f / 128.0f));
+        v[2] = (_Float16)((b_ - 127.5f) * (1.0f / 128.0f));
+        v[3] = v[4] = v[5] = v[6] = v[7] = (_Float16)0.f;
+        *reinterpret_cast<half8*>(out + i * 8) = v;
+    }
+}
+
+hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,
+                             _Float16* out, int Hc, int Wc, int rgb_in, hipStream_t stream) {
+    if (!bgr || !out || B <= 0 || H <= 0 || W <= 0 || Hc < H || Wc < W) return hipErrorInvalidValue;
+    const long total = (long)B * Hc * Wc;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, stream, bgr, B, H, W, row_stride, frame_stride,
+                       out, Hc, Wc, rgb_in);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ face list compaction
+// counts[B] -> face_slot[n] = b*max_faces + k (frame-major), n_faces.  One block.
+__global__ __launch_bounds__(256) void compact_faces_kernel(const int32_t* __restrict__ counts, int B, int max_faces,
+                                                            int32_t* __restrict__ face_slot, int32_t* __restrict__ n_faces) {
+    __shared__ int offs[1024 + 1];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { offs[b] = acc; acc += counts[b]; }
+        offs[B] = acc;
+        *n_faces = acc;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int c = counts[b], o = offs[b];
+        for (int k = 0; k < c; ++k) face_slot[o + k] = b * max_faces + k;
+    }
+}
+
+hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int32_t* face_slot, int32_t* n_faces,
+                                hipStream_t stream) {
+    if (B <= 0 || B > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(compact_faces_kernel, dim3(1), dim3(256), 0, stream, counts, B, max_faces, face_slot, n_faces);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K4
+// ArcFace 112x112 template (insightface utils/face_align.py arcface_dst)
+__constant__ float kTemplate[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f,
+                                    41.5493f, 92.3655f, 70.7299f, 92.2041f};
+
+// One workgroup per face.  Least-squares similarity (closed form of the 2-D Umeyama
+// problem: scaled rotation [[a,-b],[b,a]] + t) in double, inverse map per output pixel in
+// fp32, float bilinear with constant-0 border, RGB (x-127.5)/127.5 -> fp16 NHWC8.
+__global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
+    const int f = blockIdx.x;
+    if (f >= p.n_faces) return;
+    const int slot = p.face_slot ? p.face_slot[f] : f;
+    const int b = p.face_slot ? slot / p.max_faces : 0;
+    const float* k = p.kps + (long)slot * 10;
+    double msx = 0, msy = 0, mdx = 0, mdy = 0;
+    for (int i = 0; i < 5; ++i) { msx += k[2 * i]; msy += k[2 * i + 1]; mdx += kTemplate[2 * i]; mdy += kTemplate[2 * i + 1]; }
+    msx /= 5; msy /= 5; mdx /= 5; mdy /= 5;
+    double num_a = 0, num_b = 0, den = 0;
+    for (int i = 0; i < 5; ++i) {
+        const double sx = k[2 * i] - msx, sy = k[2 * i + 1] - msy;
+        const double dx = kTemplate[2 * i] - mdx, dy = kTemplate[2 * i + 1] - mdy;
+        num_a += sx * dx + sy * dy;
+        num_b += sx * dy - sy * dx;
+        den += sx * sx + sy * sy;
+    }
+    const bool ok = den > 1e-12 && (num_a * num_a + num_b * num_b) > 1e-24;
+    const double a = ok ? num_a / den : 1.0, bb = ok ? num_b / den : 0.0;
+    const double tx = mdx - (a * msx - bb * msy), ty = mdy - (bb * msx + a * msy);
+    // inverse: src = Minv * (dst - t)
+    const double det = a * a + bb * bb;
+    const float i00 = (float)(a / det), i01 = (float)(bb / det), i10 = (float)(-bb / det), i11 = (float)(a / det);
+    const float itx = (float)(-(a * tx + bb * ty) / det), ity = (float)(-(-bb * tx + a * ty) / det);
+    const uint8_t* img = p.frames + (long)b * p.frame_stride;
+    _Float16* out = p.chips + (long)f * (FRP_CHIP_PIX * 8);
+    const int c_r = p.rgb_in ? 0 : 2, c_b = p.rgb_in ? 2 : 0;
+    for (int i = threadIdx.x; i < FRP_CHIP_PIX; i += blockDim.x) {
+        const int v = i / 112, u = i - v * 112;
+        const float sx = i00 * (float)u + i01 * (float)v + itx;
+        const float sy = i10 * (float)u + i11 * (float)v + ity;
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float ax = sx - fx0, ay = sy - fy0;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (ok) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xx = x0 + dx, yy = y0 + dy;
+                    if ((unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H) {
+                        const float w = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
+                        const uint8_t* px = img + yy * p.row_stride + 3L * xx;
+                        acc[0] += w * (float)px[c_r];
+                        acc[1] += w * (float)px[1];
+                        acc[2] += w * (float)px[c_b];
+                    }
+                }
+            }
+        }
+        half8 o;
+        o[0] = (_Float16)((acc[0] - 127.5f) * (1.0f / 127.5f));
+        o[1] = (_Float16)((acc[1] - 127.5f) * (1.0f / 127.5f));
+        o[2] = (_Float16)((acc[2] - 127.5f) * (1.0f / 127.5f));
+        o[3] = o[4] = o[5] = o[6] = o[7] = (_Float16)0.f;
+        *reinterpret_cast<half8*>(out + (long)i * 8) = o;
+    }
+}
+
+hipError_t launch_align(const AlignParams& p, hipStream_t stream) {
+    if (p.n_faces <= 0) return hipSuccess;
+    if (!p.frames || !p.kps || !p.chips || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(align_kernel, dim3(p.n_faces), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// aligned u8 BGR chips -> blob
+__global__ __launch_bounds__(256) void chips_to_blob_kernel(const uint8_t* __restrict__ chips, long total,
+                                                            _Float16* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t* p = chips + 3 * i;
+        half8 o;
+        o[0] = (_Float16)(((float)p[2] - 127.5f) * (1.0f / 127.5f));
+        o[1] = (_Float16)(((float)p[1] - 127.5f) * (1.0f / 127.5f));
+        o[2] = (_Float16)(((float)p[0] - 127.5f) * (1.0f / 127.5f));
+        o[3] = o[4] = o[5] = o[6] = o[7] = (_Float16)0.f;
+        *reinterpret_cast<half8*>(out + i * 8) = o;
+    }
+}
+
+hipError_t launch_chips_to_blob(const uint8_t* chips, int M, _Float16* out, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    const long total = (long)M * FRP_CHIP_PIX;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(chips_to_blob_kernel, dim3(grid), dim3(256), 0, stream, chips, total, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K5 tail: one wave per row
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _Float16* __restrict__ emb16, int M, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float* e = emb + (long)row * D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) ss += e[i] * e[i];
+    ss = wave_sum(ss);
+    const float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float v = e[i] * inv;
+        e[i] = v;
+        if (emb16) emb16[(long)row * D + i] = (_Float16)v;
+    }
+}
+
+hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, emb, emb16, M, D);
+    return hipGetLastError();
+}
+
+// fp32 rows -> unit fp16 rows (gallery upload, query conversion)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
+                                                             long N, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* e = in + row * D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) ss += e[i] * e[i];
+    ss = wave_sum(ss);
+    const float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    for (int i = lane; i < D; i += 64) out[row * D + i] = (_Float16)(e[i] * inv);
+}
+
+hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream) {
+    if (N <= 0) return hipSuccess;
+    const long grid = (N + 3) / 4;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, in, out, N, D);
+    return hipGetLastError();
+}
+
+}  // namespace frp

@@ -1,0 +1,251 @@
+// K3: anchor decode + candidate selection + ordering + greedy NMS, one workgroup per frame.
+//
+// Replaces the tail of face_recognition.face_locations (backend/app/routes/camera.py:232,
+// backend/app/services/face_service.py:156) and the caller's cap `face_locations[:max_faces]`
+// (camera.py:233-235) for the anchor-dense detector: strides {8,16,32}, 2 anchors per
+// location, 15 values per anchor (logit, 4 distances, 5 x (dx,dy)).
+//
+// Ordering is total and deterministic: every anchor gets the unique 36-bit key
+//   (sortable fp16 logit bits << 20) | (0xFFFFF - anchor_index)
+// so "logit descending, ties by lower anchor index" is a plain integer order.  Candidates are
+// the anchors with logit >= logit(threshold); if more than CAP=1024 survive, an exact 3-pass
+// radix select keeps the CAP largest keys.  The candidates are bitonic-sorted in LDS and NMS
+// runs greedily in that order with a barrier only on kept boxes (<= max_faces of them).
+// All box arithmetic is fp32 with one rounding per operation (file is built with
+// -ffp-contract=off) so it reproduces the fp32 oracle bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frp_internal.h"
+
+namespace frp {
+
+#define NMS_CAP 1024
+#define NT 1024
+
+__device__ __forceinline__ unsigned sortable16(unsigned short h) {
+    return (h & 0x8000u) ? (unsigned)(unsigned short)(~h) : (unsigned)(h | 0x8000u);
+}
+
+// scalar members + select chains (runtime-indexed arrays would live in scratch)
+struct FrameView {
+    const _Float16 *h0, *h1, *h2;
+    int w0, w1, w2;
+    int e0, e1;     // cumulative anchor counts after level 0 / 1
+};
+
+__device__ __forceinline__ const _Float16* anchor_ptr(const FrameView& fv, int idx, int& level, int& x, int& y) {
+    level = idx < fv.e0 ? 0 : (idx < fv.e1 ? 1 : 2);
+    const int li = idx - (level == 0 ? 0 : (level == 1 ? fv.e0 : fv.e1));
+    const int wl = level == 0 ? fv.w0 : (level == 1 ? fv.w1 : fv.w2);
+    const _Float16* base = level == 0 ? fv.h0 : (level == 1 ? fv.h1 : fv.h2);
+    const int pos = li >> 1, a = li & 1;
+    y = pos / wl;
+    x = pos - y * wl;
+    return base + (long)pos * 32 + a * 15;
+}
+
+__global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
+    __shared__ unsigned long long keys[NMS_CAP];
+    __shared__ int hist[4096];
+    __shared__ float bx1[NMS_CAP], by1[NMS_CAP], bx2[NMS_CAP], by2[NMS_CAP], barea[NMS_CAP];
+    __shared__ unsigned char supp[NMS_CAP];
+    __shared__ int s_cnt, s_digit, s_need, s_keepn;
+    __shared__ int s_keep[FRP_MAX_FACES_CAP];
+    __shared__ int wsum[NT / 64];
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    FrameView fv;
+    fv.h0 = p.head[0] + (long)b * p.hl[0] * p.wl[0] * 32;
+    fv.h1 = p.head[1] + (long)b * p.hl[1] * p.wl[1] * 32;
+    fv.h2 = p.head[2] + (long)b * p.hl[2] * p.wl[2] * 32;
+    fv.w0 = p.wl[0]; fv.w1 = p.wl[1]; fv.w2 = p.wl[2];
+    fv.e0 = p.hl[0] * p.wl[0] * 2;
+    fv.e1 = fv.e0 + p.hl[1] * p.wl[1] * 2;
+    const int A = fv.e1 + p.hl[2] * p.wl[2] * 2;
+    const float lt = p.logit_thresh;
+
+    // ---- pass 0: count candidates
+    if (tid == 0) { s_cnt = 0; s_keepn = 0; }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < A; i += NT) {
+        int lv, x, y;
+        const _Float16* q = anchor_ptr(fv, i, lv, x, y);
+        local += ((float)q[0] >= lt) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((tid & 63) == 0) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int total = s_cnt;
+    __syncthreads();
+
+    // ---- exact radix select of the CAP-th largest key when too many candidates
+    unsigned long long T = 0ull;   // keep keys >= T
+    if (total > NMS_CAP) {
+        unsigned long long prefix = 0ull;
+        int need = NMS_CAP;
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = 24 - 12 * pass;
+            for (int i = tid; i < 4096; i += NT) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < A; i += NT) {
+                int lv, x, y;
+                const _Float16* q = anchor_ptr(fv, i, lv, x, y);
+                const _Float16 lg = q[0];
+                if ((float)lg >= lt) {
+                    const unsigned long long k = ((unsigned long long)sortable16(__builtin_bit_cast(unsigned short, lg)) << 20) |
+                                                 (unsigned long long)(0xFFFFF - i);
+                    if (pass == 0 || (k >> (shift + 12)) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xFFF)], 1);
+                }
+            }
+            __syncthreads();
+            // suffix counts: thread t owns bins 4t..4t+3; find d with cnt(>d) < need <= cnt(>=d)
+            const int b0 = tid * 4;
+            const int h0 = hist[b0], h1 = hist[b0 + 1], h2 = hist[b0 + 2], h3 = hist[b0 + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            // inclusive suffix sum over threads (higher tid = higher bins)
+            int v = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_down(v, o);
+                if ((tid & 63) + o < 64) v += n;
+            }
+            if ((tid & 63) == 0) wsum[tid >> 6] = v;
+            __syncthreads();
+            int above_waves = 0;
+            for (int w = (tid >> 6) + 1; w < NT / 64; ++w) above_waves += wsum[w];
+            const int suffix_incl = v + above_waves;   // count in bins >= 4t
+            const int above = suffix_incl - mine;      // count in bins > 4t+3
+            // scan my 4 bins from high to low
+            int c = above;
+            if (c < need && need <= c + h3) { s_digit = b0 + 3; s_need = need - c; }
+            c += h3;
+            if (c < need && need <= c + h2) { s_digit = b0 + 2; s_need = need - c; }
+            c += h2;
+            if (c < need && need <= c + h1) { s_digit = b0 + 1; s_need = need - c; }
+            c += h1;
+            if (c < need && need <= c + h0) { s_digit = b0; s_need = need - c; }
+            __syncthreads();
+            prefix = (prefix << 12) | (unsigned long long)s_digit;
+            need = s_need;
+            __syncthreads();
+        }
+        T = prefix;
+    }
+
+    // ---- gather candidates
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < NMS_CAP; i += NT) { keys[i] = 0ull; supp[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < A; i += NT) {
+        int lv, x, y;
+        const _Float16* q = anchor_ptr(fv, i, lv, x, y);
+        const _Float16 lg = q[0];
+        if ((float)lg >= lt) {
+            const unsigned long long k = ((unsigned long long)sortable16(__builtin_bit_cast(unsigned short, lg)) << 20) |
+                                         (unsigned long long)(0xFFFFF - i);
+            if (k >= T) {
+                const int s = atomicAdd(&s_cnt, 1);
+                if (s < NMS_CAP) keys[s] = k | (1ull << 40);   // bit 40 marks a real entry (> any padding 0)
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_cnt < NMS_CAP ? s_cnt : NMS_CAP;
+
+    // ---- bitonic sort, descending
+    for (int k2 = 2; k2 <= NMS_CAP; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const int i = tid;
+            const int ixj = i ^ j;
+            if (ixj > i) {
+                const unsigned long long a = keys[i], c = keys[ixj];
+                const bool desc = (i & k2) == 0;
+                if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- decode boxes of the sorted candidates
+    if (tid < n) {
+        const int idx = 0xFFFFF - (int)(keys[tid] & 0xFFFFF);
+        int lv, x, y;
+        const _Float16* q = anchor_ptr(fv, idx, lv, x, y);
+        const float s = (float)(8 << lv);
+        const float cx = (float)(x * (8 << lv)), cy = (float)(y * (8 << lv));
+        const float x1 = cx - (float)q[1] * s, y1 = cy - (float)q[2] * s;
+        const float x2 = cx + (float)q[3] * s, y2 = cy + (float)q[4] * s;
+        bx1[tid] = x1; by1[tid] = y1; bx2[tid] = x2; by2[tid] = y2;
+        barea[tid] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
+    }
+    __syncthreads();
+
+    // ---- greedy NMS in key order; barrier only when a box is kept
+    const int K = p.max_faces;
+    for (int i = 0; i < n; ++i) {
+        if (supp[i]) continue;            // uniform: written before the last barrier
+        if (tid == 0) s_keep[s_keepn] = i;
+        const int kept = s_keepn + 1;     // uniform read (updated after the barrier below)
+        if (kept >= K) { __syncthreads(); if (tid == 0) s_keepn = kept; __syncthreads(); break; }
+        const float ix1 = bx1[i], iy1 = by1[i], ix2 = bx2[i], iy2 = by2[i], ia = barea[i];
+        for (int j = i + 1 + tid; j < n; j += NT) {
+            const float xx1 = fmaxf(ix1, bx1[j]), yy1 = fmaxf(iy1, by1[j]);
+            const float xx2 = fminf(ix2, bx2[j]), yy2 = fminf(iy2, by2[j]);
+            const float w = fmaxf(0.0f, xx2 - xx1 + 1.0f), h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+            const float inter = w * h;
+            const float ovr = inter / ((ia + barea[j]) - inter);
+            if (ovr > p.nms_iou) supp[j] = 1;
+        }
+        __syncthreads();
+        if (tid == 0) s_keepn = kept;
+        __syncthreads();
+    }
+    __syncthreads();
+    const int kept = s_keepn;
+
+    // ---- outputs
+    if (tid < K) {
+        float* ob = p.boxes + ((long)b * K + tid) * 4;
+        float* ok = p.kps + ((long)b * K + tid) * 10;
+        if (tid < kept) {
+            const int c = s_keep[tid];
+            const int idx = 0xFFFFF - (int)(keys[c] & 0xFFFFF);
+            int lv, x, y;
+            const _Float16* q = anchor_ptr(fv, idx, lv, x, y);
+            const float s = (float)(8 << lv);
+            const float cx = (float)(x * (8 << lv)), cy = (float)(y * (8 << lv));
+            ob[0] = bx1[c]; ob[1] = by1[c]; ob[2] = bx2[c]; ob[3] = by2[c];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                ok[2 * t] = cx + (float)q[5 + 2 * t] * s;
+                ok[2 * t + 1] = cy + (float)q[6 + 2 * t] * s;
+            }
+            p.scores[(long)b * K + tid] = 1.0f / (1.0f + expf(-(float)q[0]));
+            if (p.anchor) p.anchor[(long)b * K + tid] = idx;
+        } else {
+            ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+            for (int t = 0; t < 10; ++t) ok[t] = 0.f;
+            p.scores[(long)b * K + tid] = 0.f;
+            if (p.anchor) p.anchor[(long)b * K + tid] = -1;
+        }
+    }
+    if (tid == 0) p.counts[b] = kept;
+}
+
+hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.max_faces <= 0 || p.max_faces > FRP_MAX_FACES_CAP) return hipErrorInvalidValue;
+    long A = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (!p.head[l] || p.hl[l] <= 0 || p.wl[l] <= 0) return hipErrorInvalidValue;
+        A += (long)p.hl[l] * p.wl[l] * 2;
+    }
+    if (A > 0xFFFFF) return hipErrorInvalidValue;   // 20-bit anchor index in the sort key
+    if (!p.boxes || !p.kps || !p.scores || !p.counts) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_nms_kernel, dim3(p.B), dim3(NT), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace frp

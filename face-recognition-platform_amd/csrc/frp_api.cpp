@@ -1,0 +1,924 @@
+// C-ABI host runtime of libfrp.so: handle, weight/program blob, gallery snapshots, the
+// detect -> align -> embed -> match pipeline on one HIP stream, per-stage HIP-event timing.
+// Interface and the reference call sites each entry point replaces: include/frp.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "frp.h"
+#include "frp_blob.h"
+#include "frp_internal.h"
+
+using namespace frp;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TensorDims {
+    int h = 0, w = 0, c = 0;
+    bool f32 = false;
+};
+
+struct Net {
+    std::vector<frp_conv_op> ops;
+    int n_bufs = 0;
+    int in_buf = 0, in_ch = 0;
+    std::vector<DevBuf> bufs;
+    std::vector<TensorDims> dims;   // per physical buffer, for the last planned shape
+};
+
+enum { EV_START = 0, EV_H2D, EV_PRE, EV_DET, EV_DEC, EV_ALIGN, EV_EMB, EV_L2, EV_MATCH, EV_D2H, EV_COUNT };
+
+}  // namespace
+
+struct frp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    frp_config cfg{};
+    // weights
+    bool have_weights = false;
+    frp_blob_header hdr{};
+    DevBuf wdata;
+    Net det, emb;
+    // resident frames (tightly packed u8 [B,H,W,3])
+    DevBuf frames;
+    int rB = 0, rH = 0, rW = 0;
+    int canvas_h = 0, canvas_w = 0;
+    // per-call results (device)
+    DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch;
+    int last_B = 0, last_K = 0, last_nfaces = 0;
+    bool last_matched = false;
+    int32_t* h_nfaces = nullptr;   // pinned
+    // gallery snapshot
+    DevBuf gallery;
+    int64_t g_rows = 0;
+    // profiling
+    hipEvent_t ev[EV_COUNT]{};
+    frp_counters ctr{};
+};
+
+namespace {
+
+int fail(frp_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(h, FRP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+#define FRPCHK(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != FRP_OK) return _r; \
+    } while (0)
+
+int ensure(frp_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return FRP_OK;
+    if (b.p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(h, FRP_ERR_OOM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return FRP_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+float logit_threshold(float t) {
+    if (!(t > 0.f)) return -INFINITY;
+    if (t >= 1.f) return INFINITY;
+    return (float)std::log((double)t / (1.0 - (double)t));
+}
+
+void rec(frp_handle* h, int which) {
+    if (h->cfg.profile) (void)hipEventRecord(h->ev[which], h->stream);
+}
+
+// Plan + run one conv program.  in dims: [batch, H, W, in_ch] already written to bufs[in_buf].
+int plan_net(frp_handle* h, Net& net, int batch, int H, int W) {
+    net.dims.assign(net.n_bufs, TensorDims());
+    std::vector<size_t> need(net.n_bufs, 0);
+    net.dims[net.in_buf] = {H, W, net.in_ch, false};
+    need[net.in_buf] = (size_t)batch * H * W * net.in_ch * 2;
+    for (const frp_conv_op& op : net.ops) {
+        TensorDims in = net.dims[op.in_buf];
+        if (in.c == 0) return fail(h, FRP_ERR_BLOB, "program reads an unwritten buffer");
+        if (op.flags & FRP_FLAG_FLATTEN) in = {1, 1, in.h * in.w * in.c, false};
+        if (in.c != op.cin) return fail(h, FRP_ERR_BLOB, "program channel mismatch");
+        const int pad = op.ksize / 2;
+        TensorDims out;
+        out.h = (in.h + 2 * pad - op.ksize) / op.stride + 1;
+        out.w = (in.w + 2 * pad - op.ksize) / op.stride + 1;
+        out.c = op.cout;
+        out.f32 = (op.flags & FRP_FLAG_OUT_F32) != 0;
+        if (out.h <= 0 || out.w <= 0) return fail(h, FRP_ERR_INVALID, "input too small for the network");
+        net.dims[op.out_buf] = out;
+        need[op.out_buf] = std::max(need[op.out_buf], (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : 2));
+    }
+    for (int i = 0; i < net.n_bufs; ++i) FRPCHK(ensure(h, net.bufs[i], need[i]));
+    return FRP_OK;
+}
+
+int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches) {
+    // dims are re-derived while walking (physical buffers are reused by several tensors)
+    std::vector<TensorDims> d(net.n_bufs);
+    d[net.in_buf] = {H, W, net.in_ch, false};
+    const char* wbase = (const char*)h->wdata.p;
+    for (const frp_conv_op& op : net.ops) {
+        TensorDims in = d[op.in_buf];
+        if (op.flags & FRP_FLAG_FLATTEN) in = {1, 1, in.h * in.w * in.c, false};
+        ConvParams p{};
+        p.x = (const _Float16*)net.bufs[op.in_buf].p;
+        p.w = (const _Float16*)(wbase + op.w_off);
+        p.bias = (const float*)(wbase + op.bias_off);
+        p.slope = op.slope_off >= 0 ? (const float*)(wbase + op.slope_off) : nullptr;
+        p.res = op.res_buf >= 0 ? (const _Float16*)net.bufs[op.res_buf].p : nullptr;
+        p.out = net.bufs[op.out_buf].p;
+        p.N = batch; p.H = in.h; p.W = in.w; p.Cin = op.cin; p.Cout = op.cout;
+        p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
+        p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
+        if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
+        hipError_t e = launch_conv(p, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_conv: ") + hipGetErrorString(e));
+        const int pad = op.ksize / 2;
+        TensorDims out;
+        out.h = (in.h + 2 * pad - op.ksize) / op.stride + 1;
+        out.w = (in.w + 2 * pad - op.ksize) / op.stride + 1;
+        out.c = op.cout;
+        out.f32 = (op.flags & FRP_FLAG_OUT_F32) != 0;
+        d[op.out_buf] = out;
+        const int cin_r = op.real_ch & 0xffff, cout_r = (op.real_ch >> 16) & 0xffff;
+        *flops += 2.0 * batch * out.h * out.w * (double)op.ksize * op.ksize * (cin_r ? cin_r : op.cin) * (cout_r ? cout_r : op.cout);
+        *launches += 1;
+    }
+    net.dims = d;
+    return FRP_OK;
+}
+
+int parse_net(frp_handle* h, const unsigned char* blob, size_t bytes, uint64_t off, uint32_t n_ops, uint32_t n_bufs,
+              uint32_t in_buf, uint32_t in_ch, uint64_t data_bytes, Net& net) {
+    if (off + (uint64_t)n_ops * sizeof(frp_conv_op) > bytes) return fail(h, FRP_ERR_BLOB, "op table out of range");
+    if (n_bufs == 0 || n_bufs > 4096 || in_buf >= n_bufs) return fail(h, FRP_ERR_BLOB, "bad buffer count");
+    for (DevBuf& b : net.bufs) release(b);
+    net.ops.resize(n_ops);
+    if (n_ops) memcpy(net.ops.data(), blob + off, (size_t)n_ops * sizeof(frp_conv_op));
+    net.n_bufs = (int)n_bufs;
+    net.in_buf = (int)in_buf;
+    net.in_ch = (int)in_ch;
+    net.bufs.assign(n_bufs, DevBuf());
+    for (const frp_conv_op& op : net.ops) {
+        if (op.in_buf < 0 || op.in_buf >= (int)n_bufs || op.out_buf < 0 || op.out_buf >= (int)n_bufs ||
+            op.res_buf >= (int)n_bufs || op.in_buf == op.out_buf || op.res_buf == op.out_buf)
+            return fail(h, FRP_ERR_BLOB, "op buffer id out of range");
+        if (!(op.ksize == 1 || op.ksize == 3) || !(op.stride == 1 || op.stride == 2) || op.cin < 8 || (op.cin & 7) ||
+            op.cout < 4 || (op.cout & 3) || op.act < 0 || op.act > 2)
+            return fail(h, FRP_ERR_BLOB, "op shape not supported");
+        const uint64_t wbytes = (uint64_t)op.cout * op.ksize * op.ksize * op.cin * 2;
+        const uint64_t bbytes = (uint64_t)op.cout * 4 * ((op.flags & FRP_FLAG_BORDER_BIAS) ? 9 : 1);
+        if (op.w_off < 0 || (uint64_t)op.w_off + wbytes > data_bytes || (op.w_off & 15) || op.bias_off < 0 ||
+            (uint64_t)op.bias_off + bbytes > data_bytes || (op.bias_off & 15))
+            return fail(h, FRP_ERR_BLOB, "op tensor offset out of range");
+        if (op.act == FRP_ACT_PRELU &&
+            (op.slope_off < 0 || (uint64_t)op.slope_off + (uint64_t)op.cout * 4 > data_bytes || (op.slope_off & 15)))
+            return fail(h, FRP_ERR_BLOB, "op slope offset out of range");
+    }
+    return FRP_OK;
+}
+
+int upload_frames(frp_handle* h, const uint8_t* bgr, int B, int H, int W, int64_t row_stride) {
+    if (!bgr || B <= 0 || H <= 0 || W <= 0 || row_stride < (int64_t)W * 3) return fail(h, FRP_ERR_INVALID, "bad frame arguments");
+    if (B > 1024) return fail(h, FRP_ERR_INVALID, "batch too large (max 1024 frames per call)");
+    FRPCHK(ensure(h, h->frames, (size_t)B * H * W * 3));
+    rec(h, EV_START);
+    HIPCHK(h, hipMemcpy2DAsync(h->frames.p, (size_t)W * 3, bgr, (size_t)row_stride, (size_t)W * 3, (size_t)B * H,
+                               hipMemcpyHostToDevice, h->stream));
+    rec(h, EV_H2D);
+    h->rB = B; h->rH = H; h->rW = W;
+    h->canvas_h = round_up(H, 32);
+    h->canvas_w = round_up(W, 32);
+    return FRP_OK;
+}
+
+int ensure_results(frp_handle* h, int B, int K) {
+    const size_t s = (size_t)B * K;
+    FRPCHK(ensure(h, h->boxes, s * 4 * 4));
+    FRPCHK(ensure(h, h->kps, s * 10 * 4));
+    FRPCHK(ensure(h, h->scores, s * 4));
+    FRPCHK(ensure(h, h->anchor, s * 4));
+    FRPCHK(ensure(h, h->counts, (size_t)B * 4));
+    FRPCHK(ensure(h, h->face_slot, s * 4));
+    FRPCHK(ensure(h, h->nfaces, 16));
+    return FRP_OK;
+}
+
+int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
+    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+    if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
+    if (K <= 0 || K > FRP_MAX_FACES_CAP) return fail(h, FRP_ERR_INVALID, "max_faces out of range");
+    const int B = h->rB, Hc = h->canvas_h, Wc = h->canvas_w;
+    FRPCHK(plan_net(h, h->det, B, Hc, Wc));
+    FRPCHK(ensure_results(h, B, K));
+    hipError_t e = launch_preprocess((const uint8_t*)h->frames.p, B, h->rH, h->rW, (long)h->rW * 3, (long)h->rH * h->rW * 3,
+                                     (_Float16*)h->det.bufs[h->det.in_buf].p, Hc, Wc, (flags & FRP_FLAG_RGB) ? 1 : 0, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+    rec(h, EV_PRE);
+    FRPCHK(run_net(h, h->det, B, Hc, Wc, &h->ctr.det_conv_flops, &h->ctr.det_conv_launches));
+    rec(h, EV_DET);
+    DecodeParams dp{};
+    for (int l = 0; l < 3; ++l) {
+        const int bi = (int)h->hdr.det_head_buf[l];
+        dp.head[l] = (const _Float16*)h->det.bufs[bi].p;
+        dp.hl[l] = h->det.dims[bi].h;
+        dp.wl[l] = h->det.dims[bi].w;
+        if (h->det.dims[bi].c != 32) return fail(h, FRP_ERR_BLOB, "detector head must have 32 channels");
+    }
+    dp.B = B;
+    dp.max_faces = K;
+    const bool forced = flags & FRP_FLAG_FORCED_K;
+    dp.logit_thresh = forced ? -INFINITY : logit_threshold(det_thresh);
+    dp.nms_iou = forced ? 2.0f : nms_iou;
+    dp.boxes = (float*)h->boxes.p; dp.kps = (float*)h->kps.p; dp.scores = (float*)h->scores.p;
+    dp.anchor = (int32_t*)h->anchor.p; dp.counts = (int32_t*)h->counts.p;
+    e = launch_decode_nms(dp, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("decode_nms: ") + hipGetErrorString(e));
+    e = launch_compact_faces((const int32_t*)h->counts.p, B, K, (int32_t*)h->face_slot.p, (int32_t*)h->nfaces.p, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("compact_faces: ") + hipGetErrorString(e));
+    rec(h, EV_DEC);
+    h->last_B = B;
+    h->last_K = K;
+    return FRP_OK;
+}
+
+// chips for n faces are in emb.bufs[in]; run embedder + l2norm (+ fp16 copy for the matcher)
+int run_embed(frp_handle* h, int n) {
+    if (n <= 0) return FRP_OK;
+    FRPCHK(run_net(h, h->emb, n, FRP_CHIP, FRP_CHIP, &h->ctr.emb_conv_flops, &h->ctr.emb_conv_launches));
+    rec(h, EV_EMB);
+    const int mpad = round_up(n, 32);
+    FRPCHK(ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2));
+    HIPCHK(h, hipMemsetAsync(h->q16.p, 0, (size_t)mpad * FRP_EMB_DIM * 2, h->stream));
+    hipError_t e = launch_l2norm((float*)h->emb.bufs[h->hdr.emb_out_buf].p, (_Float16*)h->q16.p, n, FRP_EMB_DIM, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("l2norm: ") + hipGetErrorString(e));
+    rec(h, EV_L2);
+    return FRP_OK;
+}
+
+// q16 [mpad,512] holds n unit queries -> best_idx/best_cos [n]
+int run_match(frp_handle* h, int n, float* all_scores_dev) {
+    if (n <= 0) return FRP_OK;
+    if (h->g_rows <= 0) return fail(h, FRP_ERR_NO_GALLERY, "gallery is empty");
+    const int mpad = round_up(n, 32);
+    MatchParams mp{};
+    mp.gallery = (const _Float16*)h->gallery.p;
+    mp.N = h->g_rows;
+    mp.q = (const _Float16*)h->q16.p;
+    mp.M = n;
+    mp.Mpad = mpad;
+    mp.n_wg = match_num_workgroups(h->g_rows);
+    FRPCHK(ensure(h, h->part_cos, (size_t)mp.n_wg * mpad * 4));
+    FRPCHK(ensure(h, h->part_idx, (size_t)mp.n_wg * mpad * 4));
+    FRPCHK(ensure(h, h->best_cos, (size_t)mpad * 4));
+    FRPCHK(ensure(h, h->best_idx, (size_t)mpad * 4));
+    mp.part_cos = (float*)h->part_cos.p; mp.part_idx = (int32_t*)h->part_idx.p;
+    mp.best_cos = (float*)h->best_cos.p; mp.best_idx = (int32_t*)h->best_idx.p;
+    mp.all_scores = all_scores_dev;
+    hipError_t e = launch_match(mp, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("match: ") + hipGetErrorString(e));
+    h->ctr.match_bytes += (double)h->g_rows * FRP_EMB_DIM * 2;
+    h->ctr.match_launches += 1;
+    return FRP_OK;
+}
+
+int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
+    FRPCHK(run_detect(h, K, det_thresh, nms_iou, flags));
+    const int B = h->rB;
+    int n;
+    const long A = (long)h->det.dims[h->hdr.det_head_buf[0]].h * h->det.dims[h->hdr.det_head_buf[0]].w * 2;
+    if ((flags & FRP_FLAG_FORCED_K) && A >= K) {
+        n = B * K;   // known without a device round trip
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->h_nfaces, h->nfaces.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n = *h->h_nfaces;
+        if (n < 0 || n > B * K) return fail(h, FRP_ERR_HIP, "corrupt face count");
+    }
+    h->last_nfaces = n;
+    h->last_matched = false;
+    if (n > 0) {
+        FRPCHK(plan_net(h, h->emb, n, FRP_CHIP, FRP_CHIP));
+        AlignParams ap{};
+        ap.frames = (const uint8_t*)h->frames.p;
+        ap.B = B; ap.H = h->rH; ap.W = h->rW;
+        ap.row_stride = (long)h->rW * 3;
+        ap.frame_stride = (long)h->rH * h->rW * 3;
+        ap.kps = (const float*)h->kps.p;
+        ap.counts = (const int32_t*)h->counts.p;
+        ap.max_faces = K;
+        ap.face_slot = (const int32_t*)h->face_slot.p;
+        ap.n_faces = n;
+        ap.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
+        ap.chips = (_Float16*)h->emb.bufs[h->emb.in_buf].p;
+        hipError_t e = launch_align(ap, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("align: ") + hipGetErrorString(e));
+        rec(h, EV_ALIGN);
+        FRPCHK(run_embed(h, n));
+        if (!(flags & FRP_FLAG_NO_MATCH) && h->g_rows > 0) {
+            FRPCHK(run_match(h, n, nullptr));
+            h->last_matched = true;
+        }
+        rec(h, EV_MATCH);
+    } else {
+        rec(h, EV_ALIGN); rec(h, EV_EMB); rec(h, EV_L2); rec(h, EV_MATCH);
+    }
+    h->ctr.frames += B;
+    h->ctr.faces += n;
+    return FRP_OK;
+}
+
+void accumulate_events(frp_handle* h, bool with_h2d) {
+    if (!h->cfg.profile) return;
+    auto el = [&](int a, int b) { float ms = 0.f; return hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) == hipSuccess ? (double)ms : 0.0; };
+    frp_counters& c = h->ctr;
+    if (with_h2d) c.ms_h2d += el(EV_START, EV_H2D);
+    c.ms_preprocess += el(EV_H2D, EV_PRE);
+    c.ms_det_conv += el(EV_PRE, EV_DET);
+    c.ms_decode += el(EV_DET, EV_DEC);
+    c.ms_align += el(EV_DEC, EV_ALIGN);
+    c.ms_emb_conv += el(EV_ALIGN, EV_EMB);
+    c.ms_l2norm += el(EV_EMB, EV_L2);
+    c.ms_match += el(EV_L2, EV_MATCH);
+    c.ms_total += el(with_h2d ? EV_START : EV_H2D, EV_MATCH);
+}
+
+int fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts, float* emb,
+                  int32_t* match_idx, float* match_cos) {
+    const int B = h->last_B, K = h->last_K, n = h->last_nfaces;
+    if (B <= 0) return fail(h, FRP_ERR_INVALID, "nothing to fetch");
+    const size_t s = (size_t)B * K;
+    std::vector<int32_t> cnt(B);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), h->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (boxes) HIPCHK(h, hipMemcpyAsync(boxes, h->boxes.p, s * 16, hipMemcpyDeviceToHost, h->stream));
+    if (kps) HIPCHK(h, hipMemcpyAsync(kps, h->kps.p, s * 40, hipMemcpyDeviceToHost, h->stream));
+    if (scores) HIPCHK(h, hipMemcpyAsync(scores, h->scores.p, s * 4, hipMemcpyDeviceToHost, h->stream));
+    std::vector<float> cemb;
+    std::vector<int32_t> cidx;
+    std::vector<float> ccos;
+    if (n > 0 && emb) {
+        cemb.resize((size_t)n * FRP_EMB_DIM);
+        HIPCHK(h, hipMemcpyAsync(cemb.data(), h->emb.bufs[h->hdr.emb_out_buf].p, cemb.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (n > 0 && h->last_matched && (match_idx || match_cos)) {
+        cidx.resize(n);
+        ccos.resize(n);
+        HIPCHK(h, hipMemcpyAsync(cidx.data(), h->best_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ccos.data(), h->best_cos.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (counts) memcpy(counts, cnt.data(), (size_t)B * 4);
+    if (emb) memset(emb, 0, s * FRP_EMB_DIM * 4);
+    if (match_idx) for (size_t i = 0; i < s; ++i) match_idx[i] = -1;
+    if (match_cos) for (size_t i = 0; i < s; ++i) match_cos[i] = -1.f;
+    int f = 0;
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < cnt[b] && f < n; ++k, ++f) {
+            const size_t slot = (size_t)b * K + k;
+            if (emb && !cemb.empty()) memcpy(emb + slot * FRP_EMB_DIM, cemb.data() + (size_t)f * FRP_EMB_DIM, FRP_EMB_DIM * 4);
+            if (!cidx.empty()) {
+                if (match_idx) match_idx[slot] = cidx[f];
+                if (match_cos) match_cos[slot] = ccos[f];
+            }
+        }
+    }
+    return FRP_OK;
+}
+
+int to_f32(frp_handle* h, const void* src, size_t count, int dtype, std::vector<float>& out) {
+    out.resize(count);
+    if (dtype == FRP_F32) {
+        memcpy(out.data(), src, count * 4);
+    } else if (dtype == FRP_F64) {
+        const double* d = (const double*)src;
+        for (size_t i = 0; i < count; ++i) out[i] = (float)d[i];
+    } else if (dtype == FRP_F16) {
+        const _Float16* d = (const _Float16*)src;
+        for (size_t i = 0; i < count; ++i) out[i] = (float)d[i];
+    } else {
+        return fail(h, FRP_ERR_INVALID, "unknown dtype");
+    }
+    return FRP_OK;
+}
+
+// host fp32 rows -> unit fp16 rows at dst (device), via the scratch buffer
+int upload_rows_normalized(frp_handle* h, const float* rows, int64_t n, _Float16* dst) {
+    if (n <= 0) return FRP_OK;
+    const int64_t chunk = 1 << 16;
+    FRPCHK(ensure(h, h->scratch, (size_t)std::min(n, chunk) * FRP_EMB_DIM * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t m = std::min(chunk, n - r0);
+        HIPCHK(h, hipMemcpyAsync(h->scratch.p, rows + r0 * FRP_EMB_DIM, (size_t)m * FRP_EMB_DIM * 4, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = launch_gallery_normalize((const float*)h->scratch.p, dst + r0 * FRP_EMB_DIM, m, FRP_EMB_DIM, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("gallery_normalize: ") + hipGetErrorString(e));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // scratch is reused by the next chunk
+    }
+    return FRP_OK;
+}
+
+struct Guard {
+    std::lock_guard<std::mutex> lk;
+    explicit Guard(frp_handle* h) : lk(h->mu) { (void)hipSetDevice(h->device); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* frp_version(void) { return "frp 0.1 (gfx950)"; }
+
+int frp_create(int device, const frp_config* cfg, frp_handle** out) {
+    if (!out) return FRP_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FRP_ERR_HIP;   // fail loudly: no CPU fallback
+    if (device < 0 || device >= ndev) return FRP_ERR_INVALID;
+    frp_handle* h = new (std::nothrow) frp_handle();
+    if (!h) return FRP_ERR_OOM;
+    h->device = device;
+    h->cfg.struct_size = sizeof(frp_config);
+    h->cfg.max_batch = 32; h->cfg.max_faces = 10; h->cfg.max_h = 1080; h->cfg.max_w = 1920; h->cfg.profile = 0;
+    if (cfg) {
+        if (cfg->struct_size != (int32_t)sizeof(frp_config)) { delete h; return FRP_ERR_INVALID; }
+        if (cfg->max_batch > 0) h->cfg.max_batch = cfg->max_batch;
+        if (cfg->max_faces > 0) h->cfg.max_faces = std::min<int>(cfg->max_faces, FRP_MAX_FACES_CAP);
+        if (cfg->max_h > 0) h->cfg.max_h = cfg->max_h;
+        if (cfg->max_w > 0) h->cfg.max_w = cfg->max_w;
+        h->cfg.profile = cfg->profile ? 1 : 0;
+    }
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&h->h_nfaces, 64, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { frp_destroy(h); return FRP_ERR_HIP; }
+    h->ctr.struct_size = sizeof(frp_counters);
+    *out = h;
+    return FRP_OK;
+}
+
+void frp_destroy(frp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DevBuf& b : h->det.bufs) release(b);
+    for (DevBuf& b : h->emb.bufs) release(b);
+    DevBuf* all[] = {&h->wdata, &h->frames, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
+                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->gallery};
+    for (DevBuf* b : all) release(*b);
+    for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* frp_last_error(const frp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!blob || bytes < sizeof(frp_blob_header)) return fail(h, FRP_ERR_BLOB, "blob too small");
+    frp_blob_header hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (memcmp(hd.magic, FRP_BLOB_MAGIC, 8) != 0 || hd.version != FRP_BLOB_VERSION || hd.header_bytes != sizeof(frp_blob_header))
+        return fail(h, FRP_ERR_BLOB, "bad magic/version");
+    if (hd.data_offset > bytes || hd.data_bytes > bytes - hd.data_offset) return fail(h, FRP_ERR_BLOB, "data section out of range");
+    if (hd.emb_dim != FRP_EMB_DIM || hd.emb_size != FRP_CHIP || hd.det_in_ch != 8 || hd.emb_in_ch != 8 || hd.det_num_anchors != 2)
+        return fail(h, FRP_ERR_BLOB, "unsupported network geometry");
+    h->have_weights = false;
+    const unsigned char* b = (const unsigned char*)blob;
+    FRPCHK(parse_net(h, b, bytes, hd.det_ops_offset, hd.n_det_ops, hd.n_det_bufs, hd.det_in_buf, hd.det_in_ch, hd.data_bytes, h->det));
+    FRPCHK(parse_net(h, b, bytes, hd.emb_ops_offset, hd.n_emb_ops, hd.n_emb_bufs, hd.emb_in_buf, hd.emb_in_ch, hd.data_bytes, h->emb));
+    for (int l = 0; l < 3; ++l)
+        if (hd.det_head_buf[l] >= hd.n_det_bufs) return fail(h, FRP_ERR_BLOB, "head buffer id out of range");
+    if (hd.emb_out_buf >= hd.n_emb_bufs) return fail(h, FRP_ERR_BLOB, "embedding buffer id out of range");
+    FRPCHK(ensure(h, h->wdata, hd.data_bytes));
+    HIPCHK(h, hipMemcpyAsync(h->wdata.p, b + hd.data_offset, hd.data_bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hdr = hd;
+    h->have_weights = true;
+    return FRP_OK;
+}
+
+// ---------------------------------------------------------------- gallery
+int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_t dtype) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (n < 0 || (n > 0 && !emb) || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512]");
+    DevBuf fresh;   // new snapshot, swapped in when complete
+    if (n > 0) {
+        std::vector<float> f;
+        const float* rows = (const float*)emb;
+        if (dtype != FRP_F32) { FRPCHK(to_f32(h, emb, (size_t)n * d, dtype, f)); rows = f.data(); }
+        FRPCHK(ensure(h, fresh, (size_t)n * d * 2));
+        int r = upload_rows_normalized(h, rows, n, (_Float16*)fresh.p);
+        if (r != FRP_OK) { release(fresh); return r; }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    release(h->gallery);
+    h->gallery = fresh;
+    h->g_rows = n;
+    return FRP_OK;
+}
+
+int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_t d) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (n <= 0 || !dev_f16 || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512] fp16 on the device");
+    DevBuf fresh;
+    FRPCHK(ensure(h, fresh, (size_t)n * d * 2));
+    hipError_t e = hipMemcpyAsync(fresh.p, dev_f16, (size_t)n * d * 2, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("gallery copy: ") + hipGetErrorString(e)); }
+    release(h->gallery);
+    h->gallery = fresh;
+    h->g_rows = n;
+    return FRP_OK;
+}
+
+int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!emb || d != FRP_EMB_DIM || row < 0 || row > h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
+    std::vector<float> f;
+    FRPCHK(to_f32(h, emb, (size_t)d, dtype, f));
+    if (row == h->g_rows && (size_t)(h->g_rows + 1) * d * 2 > h->gallery.cap) {
+        // grow: new snapshot with doubled capacity
+        DevBuf fresh;
+        const size_t cap_rows = std::max<int64_t>(1024, h->g_rows * 2);
+        FRPCHK(ensure(h, fresh, cap_rows * d * 2));
+        if (h->g_rows > 0) {
+            hipError_t e = hipMemcpyAsync(fresh.p, h->gallery.p, (size_t)h->g_rows * d * 2, hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("gallery grow: ") + hipGetErrorString(e)); }
+        }
+        release(h->gallery);
+        h->gallery = fresh;
+    }
+    FRPCHK(upload_rows_normalized(h, f.data(), 1, (_Float16*)h->gallery.p + row * d));
+    if (row == h->g_rows) h->g_rows += 1;
+    return FRP_OK;
+}
+
+int frp_gallery_remove_row(frp_handle* h, int64_t row) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (row < 0 || row >= h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
+    const int64_t last = h->g_rows - 1;
+    if (row != last) {
+        HIPCHK(h, hipMemcpyAsync((_Float16*)h->gallery.p + row * FRP_EMB_DIM, (_Float16*)h->gallery.p + last * FRP_EMB_DIM,
+                                 FRP_EMB_DIM * 2, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->g_rows = last;
+    return FRP_OK;
+}
+
+int64_t frp_gallery_size(const frp_handle* h) { return h ? h->g_rows : -1; }
+
+int frp_gallery_get(frp_handle* h, void* out_f16, int64_t first_row, int64_t n_rows) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!out_f16 || first_row < 0 || n_rows < 0 || first_row + n_rows > h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery range");
+    if (n_rows == 0) return FRP_OK;
+    HIPCHK(h, hipMemcpyAsync(out_f16, (_Float16*)h->gallery.p + first_row * FRP_EMB_DIM, (size_t)n_rows * FRP_EMB_DIM * 2,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+// ---------------------------------------------------------------- hot path
+int frp_upload_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    FRPCHK(upload_frames(h, bgr, B, H, W, row_stride));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_process_resident(frp_handle* h, int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    rec(h, EV_H2D);
+    FRPCHK(run_pipeline(h, max_faces, det_thresh, nms_iou, flags));
+    if (h->cfg.profile) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        accumulate_events(h, false);
+    }
+    h->ctr.calls += 1;
+    return FRP_OK;
+}
+
+int frp_synchronize(frp_handle* h) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts, float* emb,
+                      int32_t* match_idx, float* match_cos) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    return fetch_results(h, boxes, kps, scores, counts, emb, match_idx, match_cos);
+}
+
+int frp_process_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,
+                       int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags, float* boxes, float* kps,
+                       float* scores, int32_t* counts, float* emb, int32_t* match_idx, float* match_cos) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    FRPCHK(upload_frames(h, bgr, B, H, W, row_stride));
+    FRPCHK(run_pipeline(h, max_faces, det_thresh, nms_iou, flags));
+    FRPCHK(fetch_results(h, boxes, kps, scores, counts, emb, match_idx, match_cos));
+    accumulate_events(h, true);
+    h->ctr.calls += 1;
+    return FRP_OK;
+}
+
+int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride, int32_t max_faces,
+               float det_thresh, float nms_iou, uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts,
+               int32_t* anchor_idx) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    FRPCHK(upload_frames(h, bgr, B, H, W, row_stride));
+    FRPCHK(run_detect(h, max_faces, det_thresh, nms_iou, flags));
+    const size_t s = (size_t)B * max_faces;
+    if (boxes) HIPCHK(h, hipMemcpyAsync(boxes, h->boxes.p, s * 16, hipMemcpyDeviceToHost, h->stream));
+    if (kps) HIPCHK(h, hipMemcpyAsync(kps, h->kps.p, s * 40, hipMemcpyDeviceToHost, h->stream));
+    if (scores) HIPCHK(h, hipMemcpyAsync(scores, h->scores.p, s * 4, hipMemcpyDeviceToHost, h->stream));
+    if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (anchor_idx) HIPCHK(h, hipMemcpyAsync(anchor_idx, h->anchor.p, s * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->last_nfaces = 0;
+    return FRP_OK;
+}
+
+int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->have_weights || level < 0 || level > 2 || h->last_B <= 0) return fail(h, FRP_ERR_INVALID, "no head map available");
+    const int bi = (int)h->hdr.det_head_buf[level];
+    const TensorDims d = h->det.dims[bi];
+    if (hl) *hl = d.h;
+    if (wl) *wl = d.w;
+    const int64_t need = (int64_t)h->last_B * d.h * d.w * d.c * 2;
+    if (!out_f16) return FRP_OK;
+    if (out_bytes < need) return fail(h, FRP_ERR_INVALID, "head map buffer too small");
+    HIPCHK(h, hipMemcpyAsync(out_f16, h->det.bufs[bi].p, (size_t)need, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_decode_heads(frp_handle* h, const void* head8, const void* head16, const void* head32, int32_t B, int32_t canvas_h,
+                     int32_t canvas_w, int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags, float* boxes,
+                     float* kps, float* scores, int32_t* counts, int32_t* anchor_idx) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!head8 || !head16 || !head32 || B <= 0 || B > 1024 || canvas_h <= 0 || canvas_w <= 0 || (canvas_h & 31) || (canvas_w & 31) ||
+        max_faces <= 0 || max_faces > FRP_MAX_FACES_CAP)
+        return fail(h, FRP_ERR_INVALID, "bad decode arguments");
+    const void* src[3] = {head8, head16, head32};
+    DevBuf tmp[3];
+    DecodeParams dp{};
+    int rc = FRP_OK;
+    for (int l = 0; l < 3 && rc == FRP_OK; ++l) {
+        dp.hl[l] = canvas_h / (8 << l);
+        dp.wl[l] = canvas_w / (8 << l);
+        const size_t bytes = (size_t)B * dp.hl[l] * dp.wl[l] * 32 * 2;
+        rc = ensure(h, tmp[l], bytes);
+        if (rc == FRP_OK && hipMemcpyAsync(tmp[l].p, src[l], bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+            rc = fail(h, FRP_ERR_HIP, "head upload failed");
+        dp.head[l] = (const _Float16*)tmp[l].p;
+    }
+    if (rc == FRP_OK) rc = ensure_results(h, B, max_faces);
+    if (rc == FRP_OK) {
+        dp.B = B; dp.max_faces = max_faces;
+        const bool forced = flags & FRP_FLAG_FORCED_K;
+        dp.logit_thresh = forced ? -INFINITY : logit_threshold(det_thresh);
+        dp.nms_iou = forced ? 2.0f : nms_iou;
+        dp.boxes = (float*)h->boxes.p; dp.kps = (float*)h->kps.p; dp.scores = (float*)h->scores.p;
+        dp.anchor = (int32_t*)h->anchor.p; dp.counts = (int32_t*)h->counts.p;
+        hipError_t e = launch_decode_nms(dp, h->stream);
+        if (e != hipSuccess) rc = fail(h, FRP_ERR_HIP, std::string("decode_nms: ") + hipGetErrorString(e));
+    }
+    const size_t s = (size_t)B * max_faces;
+    hipError_t e = hipSuccess;
+    if (rc == FRP_OK) {
+        if (boxes) e = hipMemcpyAsync(boxes, h->boxes.p, s * 16, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && kps) e = hipMemcpyAsync(kps, h->kps.p, s * 40, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && scores) e = hipMemcpyAsync(scores, h->scores.p, s * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && counts) e = hipMemcpyAsync(counts, h->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && anchor_idx) e = hipMemcpyAsync(anchor_idx, h->anchor.p, s * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    for (int l = 0; l < 3; ++l) release(tmp[l]);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(h, FRP_ERR_HIP, "decode result copy failed");
+    return FRP_OK;
+}
+
+static int align_common(frp_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, const float* kps, int M, uint32_t flags) {
+    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+    if (!kps || M <= 0 || M > 65536) return fail(h, FRP_ERR_INVALID, "bad landmark arguments");
+    FRPCHK(upload_frames(h, bgr, 1, H, W, row_stride));
+    FRPCHK(plan_net(h, h->emb, M, FRP_CHIP, FRP_CHIP));
+    FRPCHK(ensure(h, h->kps, (size_t)M * 40));
+    HIPCHK(h, hipMemcpyAsync(h->kps.p, kps, (size_t)M * 40, hipMemcpyHostToDevice, h->stream));
+    AlignParams ap{};
+    ap.frames = (const uint8_t*)h->frames.p;
+    ap.B = 1; ap.H = H; ap.W = W;
+    ap.row_stride = (long)W * 3; ap.frame_stride = (long)H * W * 3;
+    ap.kps = (const float*)h->kps.p;
+    ap.max_faces = M;
+    ap.face_slot = nullptr;
+    ap.n_faces = M;
+    ap.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
+    ap.chips = (_Float16*)h->emb.bufs[h->emb.in_buf].p;
+    hipError_t e = launch_align(ap, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("align: ") + hipGetErrorString(e));
+    return FRP_OK;
+}
+
+int frp_align(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t row_stride, const float* kps, int32_t M,
+              uint32_t flags, void* chips_f16) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!chips_f16) return fail(h, FRP_ERR_INVALID, "null output");
+    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags));
+    HIPCHK(h, hipMemcpyAsync(chips_f16, h->emb.bufs[h->emb.in_buf].p, (size_t)M * FRP_CHIP_PIX * 8 * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_embed_faces(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t row_stride, const float* kps, int32_t M,
+                    uint32_t flags, float* emb) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!emb) return fail(h, FRP_ERR_INVALID, "null output");
+    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags));
+    FRPCHK(run_embed(h, M));
+    HIPCHK(h, hipMemcpyAsync(emb, h->emb.bufs[h->hdr.emb_out_buf].p, (size_t)M * FRP_EMB_DIM * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_embed_aligned(frp_handle* h, const uint8_t* chips, int32_t M, float* emb) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+    if (!chips || !emb || M <= 0 || M > 65536) return fail(h, FRP_ERR_INVALID, "bad chip arguments");
+    FRPCHK(plan_net(h, h->emb, M, FRP_CHIP, FRP_CHIP));
+    FRPCHK(ensure(h, h->scratch, (size_t)M * FRP_CHIP_PIX * 3));
+    HIPCHK(h, hipMemcpyAsync(h->scratch.p, chips, (size_t)M * FRP_CHIP_PIX * 3, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_chips_to_blob((const uint8_t*)h->scratch.p, M, (_Float16*)h->emb.bufs[h->emb.in_buf].p, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("chips_to_blob: ") + hipGetErrorString(e));
+    FRPCHK(run_embed(h, M));
+    HIPCHK(h, hipMemcpyAsync(emb, h->emb.bufs[h->hdr.emb_out_buf].p, (size_t)M * FRP_EMB_DIM * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+static int match_common(frp_handle* h, const float* q, int M, float* all_scores_host, int32_t* idx, float* cos) {
+    if (!q || M <= 0 || M > (1 << 20)) return fail(h, FRP_ERR_INVALID, "bad query arguments");
+    if (h->g_rows <= 0) return fail(h, FRP_ERR_NO_GALLERY, "gallery is empty");
+    const int mpad = round_up(M, 32);
+    FRPCHK(ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2));
+    HIPCHK(h, hipMemsetAsync(h->q16.p, 0, (size_t)mpad * FRP_EMB_DIM * 2, h->stream));
+    FRPCHK(upload_rows_normalized(h, q, M, (_Float16*)h->q16.p));
+    DevBuf all;
+    if (all_scores_host) FRPCHK(ensure(h, all, (size_t)M * h->g_rows * 4));
+    int rc = run_match(h, M, (float*)all.p);
+    hipError_t e = hipSuccess;
+    if (rc == FRP_OK) {
+        if (idx) e = hipMemcpyAsync(idx, h->best_idx.p, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && cos) e = hipMemcpyAsync(cos, h->best_cos.p, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && all_scores_host)
+            e = hipMemcpyAsync(all_scores_host, all.p, (size_t)M * h->g_rows * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    release(all);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(h, FRP_ERR_HIP, "match result copy failed");
+    return FRP_OK;
+}
+
+int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* idx, float* cos) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (topk != 1) return fail(h, FRP_ERR_INVALID, "topk must be 1");
+    return match_common(h, q, M, nullptr, idx, cos);
+}
+
+int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!cos_all) return fail(h, FRP_ERR_INVALID, "null output");
+    return match_common(h, q, M, cos_all, nullptr, nullptr);
+}
+
+int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t W, int32_t Cin, const void* w, int32_t Cout,
+                    int32_t ksize, int32_t stride, const float* bias, const float* slope, const void* res, int32_t res_h,
+                    int32_t res_w, int32_t act, int32_t flags, void* out) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!x || !w || !bias || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !(ksize == 1 || ksize == 3) ||
+        !(stride == 1 || stride == 2))
+        return fail(h, FRP_ERR_INVALID, "bad conv arguments");
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const bool up2 = flags & FRP_FLAG_RES_UP2;
+    const size_t xb = (size_t)N * H * W * Cin * 2, wb = (size_t)Cout * ksize * ksize * Cin * 2;
+    const size_t bb = (size_t)Cout * 4 * ((flags & FRP_FLAG_BORDER_BIAS) ? 9 : 1);
+    const size_t ob = (size_t)N * Ho * Wo * Cout * ((flags & FRP_FLAG_OUT_F32) ? 4 : 2);
+    const size_t rb = res ? (size_t)N * (up2 ? res_h : Ho) * (up2 ? res_w : Wo) * Cout * 2 : 0;
+    DevBuf dx, dw, db, ds, dr, dout;
+    int rc = ensure(h, dx, xb);
+    if (rc == FRP_OK) rc = ensure(h, dw, wb);
+    if (rc == FRP_OK) rc = ensure(h, db, bb);
+    if (rc == FRP_OK) rc = ensure(h, dout, ob);
+    if (rc == FRP_OK && slope) rc = ensure(h, ds, (size_t)Cout * 4);
+    if (rc == FRP_OK && res) rc = ensure(h, dr, rb);
+    hipError_t e = hipSuccess;
+    if (rc == FRP_OK) {
+        e = hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dw.p, w, wb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(db.p, bias, bb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && slope) e = hipMemcpyAsync(ds.p, slope, (size_t)Cout * 4, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && res) e = hipMemcpyAsync(dr.p, res, rb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            ConvParams p{};
+            p.x = (const _Float16*)dx.p; p.w = (const _Float16*)dw.p; p.bias = (const float*)db.p;
+            p.slope = slope ? (const float*)ds.p : nullptr;
+            p.res = res ? (const _Float16*)dr.p : nullptr;
+            p.out = dout.p;
+            p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
+            p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
+            p.Hr = res_h; p.Wr = res_w;
+            e = launch_conv(p, h->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout};
+    for (DevBuf* b : all) release(*b);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("conv2d: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("conv2d sync: ") + hipGetErrorString(e2));
+    return FRP_OK;
+}
+
+int frp_get_counters(frp_handle* h, frp_counters* out) {
+    if (!h || !out) return FRP_ERR_INVALID;
+    Guard g(h);
+    h->ctr.struct_size = sizeof(frp_counters);
+    h->ctr.gallery_rows = h->g_rows;
+    *out = h->ctr;
+    return FRP_OK;
+}
+
+int frp_reset_counters(frp_handle* h) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    h->ctr = frp_counters{};
+    h->ctr.struct_size = sizeof(frp_counters);
+    return FRP_OK;
+}
+
+}  // extern "C"

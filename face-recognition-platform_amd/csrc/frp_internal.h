@@ -1,0 +1,95 @@
+// Internal declarations shared by the HIP kernels and the C-ABI host code (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FRP_ACT_NONE 0
+#define FRP_ACT_RELU 1
+#define FRP_ACT_PRELU 2
+#define FRP_FLAG_BORDER_BIAS 1
+#define FRP_FLAG_OUT_F32 2
+#define FRP_FLAG_RES_UP2 4
+#define FRP_FLAG_FLATTEN 8
+#define FRP_CHIP_PIX (112 * 112)
+#ifndef FRP_MAX_FACES_CAP
+#define FRP_MAX_FACES_CAP 128
+#endif
+
+namespace frp {
+
+struct ConvParams {
+    const _Float16* x;      // [N,H,W,Cin]
+    const _Float16* w;      // [Cout][KS][KS][Cin]
+    const float* bias;      // [Cout] or [9][Cout] (FRP_FLAG_BORDER_BIAS)
+    const float* slope;     // [Cout] (PReLU) or null
+    const _Float16* res;    // [N,Ho,Wo,Cout] (or [N,Hr,Wr,Cout] with FRP_FLAG_RES_UP2) or null
+    void* out;              // [N,Ho,Wo,Cout] fp16 (fp32 with FRP_FLAG_OUT_F32)
+    int N, H, W, Cin, Cout, KS, stride;
+    int act, flags;
+    int Hr, Wr;             // residual spatial dims (RES_UP2)
+    // derived by launch_conv():
+    int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
+};
+
+hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
+
+// K1: u8 BGR frames -> normalised fp16 NHWC8 canvas (top-left letterbox, zero u8 pad)
+hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,
+                             _Float16* out, int Hc, int Wc, int rgb_in, hipStream_t stream);
+
+// K3: decode + candidate select + sort + NMS, one workgroup per frame
+struct DecodeParams {
+    const _Float16* head[3];   // per stride [B, H_l, W_l, 32]
+    int hl[3], wl[3];
+    int B, max_faces;
+    float logit_thresh, nms_iou;
+    float* boxes;     // [B, max_faces, 4]
+    float* kps;       // [B, max_faces, 10]
+    float* scores;    // [B, max_faces]
+    int32_t* anchor;  // [B, max_faces]
+    int32_t* counts;  // [B]
+};
+hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream);
+
+// K4: 5-point similarity + bilinear warp to 112x112 -> normalised fp16 NHWC8 chips
+struct AlignParams {
+    const uint8_t* frames;  // [B,H,W,3] u8 BGR
+    int B, H, W;
+    long row_stride, frame_stride;
+    const float* kps;       // [B, max_faces, 10]
+    const int32_t* counts;  // [B]
+    int max_faces;
+    const int32_t* face_slot;  // [n_faces] -> b*max_faces + k   (compacted face list)
+    int n_faces;
+    int rgb_in;             // frames are RGB instead of BGR
+    _Float16* chips;        // [n_faces,112,112,8]
+};
+hipError_t launch_align(const AlignParams& p, hipStream_t stream);
+// raw aligned u8 chips (BGR [M,112,112,3]) -> normalised fp16 NHWC8
+hipError_t launch_chips_to_blob(const uint8_t* chips, int M, _Float16* out, hipStream_t stream);
+// build the compact face list from counts (device side)
+hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int32_t* face_slot, int32_t* n_faces,
+                                hipStream_t stream);
+
+// K5 tail: row-wise L2 normalisation of [M,512] fp32 (in place) + fp16 copy for the matcher
+hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream);
+// gallery upload: fp32 rows -> unit fp16 rows
+hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
+
+// K6: cosine match, top-1 (and optional full score matrix)
+struct MatchParams {
+    const _Float16* gallery;  // [N, 512] unit rows
+    long N;
+    const _Float16* q;        // [Mpad, 512] (rows >= M zero)
+    int M, Mpad;
+    float* part_cos;          // [n_wg, Mpad]
+    int32_t* part_idx;        // [n_wg, Mpad]
+    float* best_cos;          // [M]
+    int32_t* best_idx;        // [M]
+    float* all_scores;        // [M, N] or null
+    int n_wg;
+};
+int match_num_workgroups(long N);
+hipError_t launch_match(const MatchParams& p, hipStream_t stream);
+
+}  // namespace frp

@@ -1,0 +1,309 @@
+"""ctypes binding of libfrp.so (C ABI: include/frp.h).  No CPU fallback: if the library
+or a GPU is missing every constructor raises -- the product path never routes around HIP."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrp.so")
+
+EMB_DIM = 512
+CHIP = 112
+MAX_FACES_CAP = 128
+FLAG_FORCED_K, FLAG_RGB, FLAG_NO_MATCH = 1, 2, 4
+F32, F16, F64 = 0, 1, 2
+
+ABI_SYMBOLS = [
+    "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
+    "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_update_row", "frp_gallery_remove_row",
+    "frp_gallery_size", "frp_gallery_get",
+    "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
+    "frp_detect", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_get_counters", "frp_reset_counters",
+]
+
+
+class FrpConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("max_batch", C.c_int32), ("max_faces", C.c_int32),
+                ("max_h", C.c_int32), ("max_w", C.c_int32), ("profile", C.c_int32), ("reserved", C.c_int32 * 10)]
+
+
+class FrpCounters(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("calls", C.c_int32), ("frames", C.c_int64), ("faces", C.c_int64),
+                ("ms_h2d", C.c_double), ("ms_preprocess", C.c_double), ("ms_det_conv", C.c_double),
+                ("ms_decode", C.c_double), ("ms_align", C.c_double), ("ms_emb_conv", C.c_double),
+                ("ms_l2norm", C.c_double), ("ms_match", C.c_double), ("ms_d2h", C.c_double), ("ms_total", C.c_double),
+                ("det_conv_flops", C.c_double), ("emb_conv_flops", C.c_double),
+                ("det_conv_launches", C.c_int64), ("emb_conv_launches", C.c_int64),
+                ("match_bytes", C.c_double), ("match_launches", C.c_int64), ("gallery_rows", C.c_int64),
+                ("reserved", C.c_double * 8)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("reserved", "struct_size")}
+
+
+class FrpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"frp error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libfrp.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `make -C {os.path.join(_HERE, 'csrc')}`")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+    lib.frp_create.argtypes = [C.c_int, C.POINTER(FrpConfig), C.POINTER(vp)]
+    lib.frp_destroy.argtypes = [vp]
+    lib.frp_destroy.restype = None
+    lib.frp_last_error.argtypes = [vp]
+    lib.frp_last_error.restype = C.c_char_p
+    lib.frp_version.restype = C.c_char_p
+    lib.frp_load_weights.argtypes = [vp, vp, C.c_size_t]
+    lib.frp_gallery_set.argtypes = [vp, vp, i64, i32, i32]
+    lib.frp_gallery_set_device.argtypes = [vp, vp, i64, i32]
+    lib.frp_gallery_update_row.argtypes = [vp, i64, vp, i32, i32]
+    lib.frp_gallery_remove_row.argtypes = [vp, i64]
+    lib.frp_gallery_size.argtypes = [vp]
+    lib.frp_gallery_size.restype = i64
+    lib.frp_gallery_get.argtypes = [vp, vp, i64, i64]
+    lib.frp_process_frames.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
+    lib.frp_upload_frames.argtypes = [vp, vp, i32, i32, i32, i64]
+    lib.frp_process_resident.argtypes = [vp, i32, f32, f32, u32]
+    lib.frp_fetch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.frp_synchronize.argtypes = [vp]
+    lib.frp_detect.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp]
+    lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.frp_decode_heads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
+    lib.frp_align.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
+    lib.frp_embed_aligned.argtypes = [vp, vp, i32, vp]
+    lib.frp_embed_faces.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
+    lib.frp_match.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.frp_match_scores.argtypes = [vp, vp, i32, vp]
+    lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
+    lib.frp_reset_counters.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One handle = one GPU + one stream (include/frp.h).  Thread-safe (library mutex);
+    ctypes releases the GIL for the duration of every call."""
+
+    def __init__(self, device: int = 0, max_batch: int = 32, max_faces: int = 10, max_h: int = 1080,
+                 max_w: int = 1920, profile: bool = False):
+        self._lib = load_library()
+        cfg = FrpConfig()
+        cfg.struct_size = C.sizeof(FrpConfig)
+        cfg.max_batch, cfg.max_faces, cfg.max_h, cfg.max_w, cfg.profile = max_batch, max_faces, max_h, max_w, int(profile)
+        h = C.c_void_p()
+        rc = self._lib.frp_create(device, C.byref(cfg), C.byref(h))
+        if rc != 0 or not h.value:
+            raise FrpError(rc, "frp_create failed (no usable HIP device?)")
+        self._h = h
+        self.device = device
+        self.max_faces = max_faces
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.frp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise FrpError(rc, (self._lib.frp_last_error(self._h) or b"").decode("utf-8", "replace"))
+
+    # -- weights / gallery
+    def load_weights(self, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._chk(self._lib.frp_load_weights(self._h, C.cast(buf, C.c_void_p), len(blob)))
+
+    def gallery_set(self, emb: np.ndarray):
+        emb = np.ascontiguousarray(emb)
+        if emb.size == 0:
+            self._chk(self._lib.frp_gallery_set(self._h, None, 0, EMB_DIM, F32))
+            return
+        dt = {np.dtype(np.float32): F32, np.dtype(np.float16): F16, np.dtype(np.float64): F64}.get(emb.dtype)
+        if dt is None:
+            emb, dt = emb.astype(np.float32), F32
+        self._chk(self._lib.frp_gallery_set(self._h, _ptr(emb), emb.shape[0], emb.shape[1], dt))
+
+    def gallery_set_device(self, dev_ptr: int, n: int):
+        self._chk(self._lib.frp_gallery_set_device(self._h, C.c_void_p(dev_ptr), n, EMB_DIM))
+
+    def gallery_update_row(self, row: int, emb: np.ndarray):
+        e = np.ascontiguousarray(emb, dtype=np.float32).reshape(-1)
+        self._chk(self._lib.frp_gallery_update_row(self._h, row, _ptr(e), e.shape[0], F32))
+
+    def gallery_remove_row(self, row: int):
+        self._chk(self._lib.frp_gallery_remove_row(self._h, row))
+
+    def gallery_size(self) -> int:
+        return int(self._lib.frp_gallery_size(self._h))
+
+    def gallery_get(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = self.gallery_size() - first if n is None else n
+        out = np.empty((n, EMB_DIM), dtype=np.float16)
+        self._chk(self._lib.frp_gallery_get(self._h, _ptr(out), first, n))
+        return out
+
+    # -- hot path
+    @staticmethod
+    def _frames(frames: np.ndarray) -> Tuple[np.ndarray, int, int, int, int]:
+        if frames.ndim == 3:
+            frames = frames[None]
+        if frames.ndim != 4 or frames.shape[3] != 3 or frames.dtype != np.uint8:
+            raise ValueError("frames must be uint8 [B,H,W,3]")
+        frames = np.ascontiguousarray(frames)
+        B, H, W, _ = frames.shape
+        return frames, B, H, W, W * 3
+
+    @staticmethod
+    def _alloc(B, K):
+        return dict(boxes=np.zeros((B, K, 4), np.float32), kps=np.zeros((B, K, 5, 2), np.float32),
+                    scores=np.zeros((B, K), np.float32), counts=np.zeros((B,), np.int32),
+                    emb=np.zeros((B, K, EMB_DIM), np.float32), match_idx=np.full((B, K), -1, np.int32),
+                    match_cos=np.full((B, K), -1.0, np.float32))
+
+    def process_frames(self, frames: np.ndarray, max_faces: int = 10, det_thresh: float = 0.5, nms_iou: float = 0.4,
+                       flags: int = 0) -> dict:
+        frames, B, H, W, rs = self._frames(frames)
+        o = self._alloc(B, max_faces)
+        self._chk(self._lib.frp_process_frames(self._h, _ptr(frames), B, H, W, rs, max_faces, det_thresh, nms_iou, flags,
+                                               _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]),
+                                               _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
+        return o
+
+    def upload_frames(self, frames: np.ndarray):
+        frames, B, H, W, rs = self._frames(frames)
+        self._chk(self._lib.frp_upload_frames(self._h, _ptr(frames), B, H, W, rs))
+        self._resident = (B, H, W)
+
+    def process_resident(self, max_faces: int = 10, det_thresh: float = 0.5, nms_iou: float = 0.4, flags: int = 0):
+        self._chk(self._lib.frp_process_resident(self._h, max_faces, det_thresh, nms_iou, flags))
+        self._last_k = max_faces
+
+    def synchronize(self):
+        self._chk(self._lib.frp_synchronize(self._h))
+
+    def fetch_results(self) -> dict:
+        B = self._resident[0]
+        o = self._alloc(B, self._last_k)
+        self._chk(self._lib.frp_fetch_results(self._h, _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]),
+                                              _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
+        return o
+
+    # -- stages
+    def detect(self, frames: np.ndarray, max_faces: int = 10, det_thresh: float = 0.5, nms_iou: float = 0.4, flags: int = 0):
+        frames, B, H, W, rs = self._frames(frames)
+        o = self._alloc(B, max_faces)
+        anchor = np.full((B, max_faces), -1, np.int32)
+        self._chk(self._lib.frp_detect(self._h, _ptr(frames), B, H, W, rs, max_faces, det_thresh, nms_iou, flags,
+                                       _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]), _ptr(anchor)))
+        o["anchor_idx"] = anchor
+        self._det_batch = B
+        return o
+
+    def head_maps(self):
+        """fp16 head maps [B,H_l,W_l,32] of the last detect/process call, strides 8/16/32."""
+        outs = []
+        for lv in range(3):
+            hl, wl = C.c_int32(), C.c_int32()
+            self._chk(self._lib.frp_get_head_map(self._h, lv, None, 0, C.byref(hl), C.byref(wl)))
+            a = np.empty((self._det_batch, hl.value, wl.value, 32), dtype=np.float16)
+            self._chk(self._lib.frp_get_head_map(self._h, lv, _ptr(a), a.nbytes, C.byref(hl), C.byref(wl)))
+            outs.append(a)
+        return outs
+
+    def decode_heads(self, heads, canvas_hw, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
+        hs = [np.ascontiguousarray(x, dtype=np.float16) for x in heads]
+        B = hs[0].shape[0]
+        o = self._alloc(B, max_faces)
+        anchor = np.full((B, max_faces), -1, np.int32)
+        self._chk(self._lib.frp_decode_heads(self._h, _ptr(hs[0]), _ptr(hs[1]), _ptr(hs[2]), B, canvas_hw[0], canvas_hw[1],
+                                             max_faces, det_thresh, nms_iou, flags, _ptr(o["boxes"]), _ptr(o["kps"]),
+                                             _ptr(o["scores"]), _ptr(o["counts"]), _ptr(anchor)))
+        o["anchor_idx"] = anchor
+        return o
+
+    def align(self, frame: np.ndarray, kps: np.ndarray, flags: int = 0) -> np.ndarray:
+        frames, _, H, W, rs = self._frames(frame)
+        k = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 10)
+        out = np.empty((k.shape[0], CHIP, CHIP, 8), dtype=np.float16)
+        self._chk(self._lib.frp_align(self._h, _ptr(frames), H, W, rs, _ptr(k), k.shape[0], flags, _ptr(out)))
+        return out
+
+    def embed_aligned(self, chips_bgr_u8: np.ndarray) -> np.ndarray:
+        c = np.ascontiguousarray(chips_bgr_u8, dtype=np.uint8).reshape(-1, CHIP, CHIP, 3)
+        out = np.empty((c.shape[0], EMB_DIM), dtype=np.float32)
+        self._chk(self._lib.frp_embed_aligned(self._h, _ptr(c), c.shape[0], _ptr(out)))
+        return out
+
+    def embed_faces(self, frame: np.ndarray, kps: np.ndarray, flags: int = 0) -> np.ndarray:
+        frames, _, H, W, rs = self._frames(frame)
+        k = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 10)
+        out = np.empty((k.shape[0], EMB_DIM), dtype=np.float32)
+        self._chk(self._lib.frp_embed_faces(self._h, _ptr(frames), H, W, rs, _ptr(k), k.shape[0], flags, _ptr(out)))
+        return out
+
+    def match(self, q: np.ndarray):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, EMB_DIM)
+        idx = np.empty((q.shape[0],), np.int32)
+        cos = np.empty((q.shape[0],), np.float32)
+        self._chk(self._lib.frp_match(self._h, _ptr(q), q.shape[0], 1, _ptr(idx), _ptr(cos)))
+        return idx, cos
+
+    def match_scores(self, q: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, EMB_DIM)
+        out = np.empty((q.shape[0], self.gallery_size()), np.float32)
+        self._chk(self._lib.frp_match_scores(self._h, _ptr(q), q.shape[0], _ptr(out)))
+        return out
+
+    def conv2d(self, x, w, bias, stride=1, act=0, slope=None, res=None, flags=0):
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        w = np.ascontiguousarray(w, dtype=np.float16)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        N, H, W, Cin = x.shape
+        Cout, k = w.shape[0], w.shape[1]
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = np.empty((N, Ho, Wo, Cout), dtype=np.float32 if (flags & 2) else np.float16)
+        rh = rw = 0
+        if res is not None:
+            res = np.ascontiguousarray(res, dtype=np.float16)
+            rh, rw = res.shape[1], res.shape[2]
+        if slope is not None:
+            slope = np.ascontiguousarray(slope, dtype=np.float32)
+        self._chk(self._lib.frp_conv2d_nhwc(self._h, _ptr(x), N, H, W, Cin, _ptr(w), Cout, k, stride, _ptr(bias), _ptr(slope),
+                                            _ptr(res), rh, rw, act, flags, _ptr(out)))
+        return out
+
+    def counters(self) -> dict:
+        c = FrpCounters()
+        self._chk(self._lib.frp_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._chk(self._lib.frp_reset_counters(self._h))

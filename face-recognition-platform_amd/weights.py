@@ -1,0 +1,226 @@
+"""Raw weights -> folded fp16 program blob for the native runtime.
+
+* `make_synthetic_raw(...)`: seeded synthetic raw parameters (no pretrained
+  packs exist offline).  Names follow the public PyTorch
+  conventions (`conv.weight` OIHW, `bn.{weight,bias,running_mean,running_var}`,
+  IResNet names as in the public arcface_torch `iresnet` state_dict), so a
+  loader for real checkpoints only has to produce the same dict.
+* `pack_blob(raw, ...)`: folds every BatchNorm into its conv in fp32 (post-conv
+  BN: scale into the weights + bias; pre-conv BN (IResNet bn1): scale into the
+  weights per input channel, shift folded *exactly* as 9 border-class bias
+  vectors because zero padding removes taps at the image border), casts to
+  fp16 [Cout][kh][kw][Cin], assigns activation buffers by liveness and writes
+  the blob `frp_load_weights` consumes (layout: include/frp_blob.h).
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import netspec as ns
+
+BN_EPS = 1e-5
+BLOB_MAGIC = b"FRPBLOB1"
+BLOB_VERSION = 1
+HEADER_FMT = "<8sII" + "IIII" + "III" + "I" + "IIII" + "IIII" + "QQQQ" + "QQ"
+HEADER_BYTES = struct.calcsize(HEADER_FMT)
+OP_FMT = "<iiiiiiiiiiqqq"
+OP_BYTES = struct.calcsize(OP_FMT)
+assert HEADER_BYTES == 128 and OP_BYTES == 64
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def _bn(raw: Dict[str, np.ndarray], seed: int, name: str, c: int, gamma_scale: float = 1.0):
+    r = _rng(seed, name)
+    raw[name + ".weight"] = (r.uniform(0.9, 1.1, c) * gamma_scale).astype(np.float32)
+    raw[name + ".bias"] = (r.standard_normal(c) * 0.05).astype(np.float32)
+    raw[name + ".running_mean"] = (r.standard_normal(c) * 0.05).astype(np.float32)
+    raw[name + ".running_var"] = r.uniform(0.9, 1.1, c).astype(np.float32)
+
+
+def make_synthetic_raw(seed: int = 7, det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3),
+                       want_det: bool = True, want_emb: bool = True) -> Dict[str, np.ndarray]:
+    """Variance-preserving seeded init; residual-branch-last BN gammas are scaled
+    down so the fp16 residual streams stay O(1)-O(10)."""
+    raw: Dict[str, np.ndarray] = {}
+    layers: List[ns.ConvLayer] = []
+    if want_det:
+        layers += ns.detector_layers(det_blocks)
+    if want_emb:
+        layers += ns.iresnet_layers(emb_blocks)
+    for l in layers:
+        cin = l.cin_real or l.cin
+        cout = l.cout_real or l.cout
+        r = _rng(seed, l.name)
+        is_det = l.name.startswith("det.")
+        gain = np.sqrt(2.0) if (is_det and l.act == ns.ACT_RELU) else 1.0
+        if l.name == "emb.fc":
+            w = r.standard_normal((cout, cin), dtype=np.float32) * np.float32(1.0 / np.sqrt(cin))
+            raw["emb.fc.weight"] = w
+            raw["emb.fc.bias"] = (r.standard_normal(cout) * 0.05).astype(np.float32)
+        else:
+            fan_in = cin * l.k * l.k
+            w = r.standard_normal((cout, cin, l.k, l.k), dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
+            raw[l.name + ".weight"] = w
+            if l.conv_bias:
+                raw[l.name + ".bias"] = (r.standard_normal(cout) * 0.05).astype(np.float32)
+        if l.pre_bn:
+            _bn(raw, seed, l.pre_bn, cin if l.name != "emb.fc" else 512)
+        if l.post_bn:
+            branch_last = l.res is not None and not (l.flags & ns.FLAG_RES_UP2)
+            gs = (0.5 if is_det else 0.25) if branch_last else 1.0
+            _bn(raw, seed, l.post_bn, cout, gs)
+        if l.prelu:
+            raw[l.prelu + ".weight"] = _rng(seed, l.prelu).uniform(0.15, 0.35, cout).astype(np.float32)
+    return raw
+
+
+def _bn_affine(raw, name) -> Tuple[np.ndarray, np.ndarray]:
+    g = raw[name + ".weight"].astype(np.float64)
+    b = raw[name + ".bias"].astype(np.float64)
+    m = raw[name + ".running_mean"].astype(np.float64)
+    v = raw[name + ".running_var"].astype(np.float64)
+    s = g / np.sqrt(v + BN_EPS)
+    return s, b - m * s
+
+
+def fold_layer(raw: Dict[str, np.ndarray], l: ns.ConvLayer):
+    """-> (w fp16 [cout][k][k][cin], bias fp32 [cout] or [9][cout], slope fp32 [cout] or None)"""
+    cin_r = l.cin_real or l.cin
+    cout_r = l.cout_real or l.cout
+    if l.name == "emb.fc":
+        # FC weight [512, C*7*7] with PyTorch flatten order (c, y, x) -> OIHW view [512, C, 7, 7]
+        C = 512
+        W = raw["emb.fc.weight"].astype(np.float64).reshape(cout_r, C, 7, 7)
+        k_eff = 7
+    else:
+        W = raw[l.name + ".weight"].astype(np.float64)
+        k_eff = l.k
+    b = raw[l.name + ".bias"].astype(np.float64) if l.conv_bias else np.zeros(cout_r)
+    T = np.zeros((cout_r, k_eff, k_eff))
+    if l.pre_bn:
+        s_in, t_in = _bn_affine(raw, l.pre_bn)
+        T = np.einsum("ochw,c->ohw", W, t_in)
+        W = W * s_in[None, :, None, None]
+    if l.post_bn:
+        s_out, t_out = _bn_affine(raw, l.post_bn)
+    else:
+        s_out, t_out = np.ones(cout_r), np.zeros(cout_r)
+    W = W * s_out[:, None, None, None]
+    if l.flags & ns.FLAG_BORDER_BIAS:
+        assert l.k == 3 and l.stride == 1
+        bias = np.zeros((9, l.cout))
+        for cy in range(3):
+            for cx in range(3):
+                valid = np.ones((3, 3), dtype=bool)
+                if cy == 0:
+                    valid[0, :] = False
+                if cy == 2:
+                    valid[2, :] = False
+                if cx == 0:
+                    valid[:, 0] = False
+                if cx == 2:
+                    valid[:, 2] = False
+                bias[cy * 3 + cx, :cout_r] = s_out * (b + (T * valid[None]).sum(axis=(1, 2))) + t_out
+    else:
+        bias = np.zeros((l.cout,))
+        bias[:cout_r] = s_out * (b + T.sum(axis=(1, 2))) + t_out
+    if l.name == "emb.fc":
+        # -> [cout][y][x][c] flattened: matches the NHWC [7,7,512] activation viewed as 1x1x25088
+        Wp = np.transpose(W, (0, 2, 3, 1)).reshape(cout_r, 1, 1, 7 * 7 * 512)
+        w16 = np.zeros((l.cout, 1, 1, l.cin), dtype=np.float16)
+        w16[:cout_r] = Wp.astype(np.float16)
+    else:
+        w16 = np.zeros((l.cout, l.k, l.k, l.cin), dtype=np.float16)
+        w16[:cout_r, :, :, :cin_r] = np.transpose(W, (0, 2, 3, 1)).astype(np.float16)
+    slope = None
+    if l.act == ns.ACT_PRELU:
+        slope = np.zeros((l.cout,), dtype=np.float32)
+        slope[:cout_r] = raw[l.prelu + ".weight"]
+    return w16, bias.astype(np.float32), slope
+
+
+def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[str, int], int]:
+    """Greedy liveness-based mapping logical tensor -> physical buffer id.
+    `pinned` tensors (network inputs/outputs) get private buffers."""
+    last_use: Dict[str, int] = {}
+    for i, l in enumerate(layers):
+        last_use[l.src] = i
+        if l.res:
+            last_use[l.res] = i
+    phys: Dict[str, int] = {}
+    free: List[int] = []
+    n = 0
+    for p in pinned:
+        phys[p] = n
+        n += 1
+    for i, l in enumerate(layers):
+        if l.dst not in phys:
+            if free:
+                phys[l.dst] = free.pop(0)
+            else:
+                phys[l.dst] = n
+                n += 1
+        # release tensors whose last use is this op (after allocating dst: in/out never alias)
+        for t in {l.src, l.res}:
+            if t and t not in pinned and last_use.get(t) == i and t in phys:
+                free.append(phys[t])
+    return phys, n
+
+
+def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3)) -> bytes:
+    det = ns.detector_layers(det_blocks)
+    emb = ns.iresnet_layers(emb_blocks)
+    data = bytearray()
+
+    def put(arr: np.ndarray) -> int:
+        pad = (-len(data)) % 256
+        data.extend(b"\0" * pad)
+        off = len(data)
+        data.extend(np.ascontiguousarray(arr).tobytes())
+        return off
+
+    def pack_ops(layers, pinned):
+        phys, nb = assign_buffers(layers, pinned)
+        ops = bytearray()
+        for l in layers:
+            w16, bias, slope = fold_layer(raw, l)
+            w_off = put(w16)
+            b_off = put(bias)
+            s_off = put(slope) if slope is not None else -1
+            ops += struct.pack(OP_FMT, phys[l.src], phys[l.dst], phys[l.res] if l.res else -1,
+                               l.cin, l.cout, l.k, l.stride, l.act, l.flags,
+                               (l.cin_real or l.cin) | ((l.cout_real or l.cout) << 16), w_off, b_off, s_off)
+        return bytes(ops), phys, nb
+
+    det_ops, det_phys, det_nb = pack_ops(det, ["det.in", "det.out3", "det.out4", "det.out5"])
+    emb_ops, emb_phys, emb_nb = pack_ops(emb, ["emb.in", "emb.out"])
+    det_macs, _ = ns.layer_macs(det, 1088, 1920, "det.in")
+    emb_macs, _ = ns.layer_macs(emb, ns.EMB_SIZE, ns.EMB_SIZE, "emb.in")
+    det_ops_off = HEADER_BYTES
+    emb_ops_off = det_ops_off + len(det_ops)
+    data_off = emb_ops_off + len(emb_ops)
+    data_off += (-data_off) % 256
+    hdr = struct.pack(
+        HEADER_FMT, BLOB_MAGIC, BLOB_VERSION, HEADER_BYTES,
+        len(det), det_nb, det_phys["det.in"], ns.DET_IN_CH,
+        det_phys["det.out3"], det_phys["det.out4"], det_phys["det.out5"],
+        ns.DET_NUM_ANCHORS,
+        len(emb), emb_nb, emb_phys["emb.in"], ns.EMB_IN_CH,
+        emb_phys["emb.out"], ns.EMB_SIZE, ns.EMB_DIM, 0,
+        det_ops_off, emb_ops_off, data_off, len(data),
+        det_macs, emb_macs)
+    out = bytearray(hdr) + det_ops + emb_ops
+    out.extend(b"\0" * (data_off - len(out)))
+    out += data
+    return bytes(out)
+
+
+def synthetic_blob(seed: int = 7, det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3)) -> bytes:
+    return pack_blob(make_synthetic_raw(seed, det_blocks, emb_blocks), det_blocks, emb_blocks)

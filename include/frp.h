@@ -1,0 +1,179 @@
+/* frp.h -- C ABI of the MI355X-native face-recognition hot path (libfrp.so).
+ *
+ * Drop-in boundary for the detect -> align -> embed -> match loop behind
+ * backend/app/services/face_service.py of achiever04/face-recognition-platform.
+ * The reference is pure Python and calls into un-vendored native packages; each
+ * entry point below names the reference interface (file:line under /root/reference)
+ * it replaces.  Plain C types only, no exceptions cross this boundary, every
+ * function returns 0 on success or a negative frp_status; the message for the last
+ * failure on a handle is available from frp_last_error().
+ *
+ * Ownership: the caller allocates and owns every in/out buffer (host pointers unless
+ * the name says _device); the library owns what frp_create / frp_load_weights /
+ * frp_gallery_* allocate and frees it in frp_destroy.
+ * Threading: one handle = one HIP device + one private stream; calls on a handle are
+ * serialised by an internal mutex (the reference fans out over a 4-thread pool,
+ * backend/app/routes/camera.py:30,277-279 -- use one handle per GPU instead).
+ * Gallery updates build a new device snapshot and swap it in, so a reader never sees
+ * a half-updated matrix (the reference mutates state.ENCODINGS unlocked,
+ * face_service.py:374,522).
+ */
+#ifndef FRP_H
+#define FRP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRP_EMB_DIM 512      /* embedding width (reference: 128-d dlib, face_service.py:179) */
+#define FRP_CHIP 112         /* aligned face chip edge */
+#define FRP_KPS 5            /* landmarks per face */
+#define FRP_MAX_FACES_CAP 128/* upper bound for max_faces per frame */
+
+typedef enum frp_status {
+    FRP_OK = 0,
+    FRP_ERR_INVALID = -1,     /* bad argument / shape the kernels do not cover */
+    FRP_ERR_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
+    FRP_ERR_NO_WEIGHTS = -3,  /* frp_load_weights has not succeeded on this handle */
+    FRP_ERR_NO_GALLERY = -4,  /* match requested with an empty gallery */
+    FRP_ERR_BLOB = -5,        /* malformed weight blob */
+    FRP_ERR_OOM = -6
+} frp_status;
+
+typedef enum frp_dtype { FRP_F32 = 0, FRP_F16 = 1, FRP_F64 = 2 } frp_dtype;
+
+/* process flags */
+#define FRP_FLAG_FORCED_K 1u   /* take the top max_faces anchors by score: no threshold, no NMS
+                                  (benchmark mode) */
+#define FRP_FLAG_RGB 2u        /* input frames are RGB (face_recognition.load_image_file order,
+                                  face_service.py:139) instead of BGR (cv2 capture order, camera.py:205) */
+#define FRP_FLAG_NO_MATCH 4u   /* skip the gallery match (encode_face path, face_service.py:87-219) */
+
+typedef struct frp_handle frp_handle;
+
+typedef struct frp_config {
+    int32_t struct_size;   /* sizeof(frp_config) */
+    int32_t max_batch;     /* frames per call, default 32 */
+    int32_t max_faces;     /* faces kept per frame, default 10 (camera.py:182,233-235) */
+    int32_t max_h, max_w;  /* largest frame, default 1080 x 1920 */
+    int32_t profile;       /* 1: time every stage with HIP events on the handle's stream */
+    int32_t reserved[10];
+} frp_config;
+
+/* Per-stage GPU time (HIP events on the handle's stream, accumulated over calls since
+ * the last frp_reset_counters; only filled when frp_config.profile = 1) and algorithmic work. */
+typedef struct frp_counters {
+    int32_t struct_size;
+    int32_t calls;
+    int64_t frames, faces;
+    double ms_h2d, ms_preprocess, ms_det_conv, ms_decode, ms_align, ms_emb_conv, ms_l2norm, ms_match, ms_d2h;
+    double ms_total;          /* first to last event of each call, summed */
+    double det_conv_flops;    /* algorithmic 2*MAC of the detector conv launches (padding excluded) */
+    double emb_conv_flops;    /* same for the embedder */
+    int64_t det_conv_launches, emb_conv_launches;
+    double match_bytes;       /* algorithmic gallery bytes streamed by the match kernel */
+    int64_t match_launches;
+    int64_t gallery_rows;
+    double reserved[8];
+} frp_counters;
+
+/* ---- lifecycle ------------------------------------------------------------------
+ * replaces: module singleton construction `face_service = FaceService()`
+ * (face_service.py:54-82,769) and the lazy model registry (state.py:135-259). */
+int frp_create(int device, const frp_config* cfg, frp_handle** out);
+void frp_destroy(frp_handle* h);
+const char* frp_last_error(const frp_handle* h); /* valid until the next call on h */
+const char* frp_version(void);
+
+/* Weight blob (layout: include/frp_blob.h; produced by weights.pack_blob):
+ * folded fp16 conv programs of the detector and the embedder.
+ * replaces: insightface FaceAnalysis model-pack loading (deepfake_utils.py:39-51). */
+int frp_load_weights(frp_handle* h, const void* blob, size_t bytes);
+
+/* ---- gallery (watchlist embedding matrix) -----------------------------------------
+ * replaces: state.ENCODINGS dict name -> list[float] (state.py:78) and its per-call
+ * rebuild np.array([ENCODINGS[t] ...]) (face_service.py:409,461,558,595).
+ * Rows are L2-normalised and stored as fp16 [N x 512] in HBM; names stay on the host. */
+int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_t dtype);
+/* rows already unit-norm fp16 in device memory of this handle's GPU (e.g. the output
+ * of an RCCL all-gather); copied into a library-owned snapshot */
+int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_t d);
+int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype); /* row == size appends */
+int frp_gallery_remove_row(frp_handle* h, int64_t row); /* last row moves into `row` (store/delete: face_service.py:374,522) */
+int64_t frp_gallery_size(const frp_handle* h);
+/* copy the normalised fp16 gallery back to the host (n_rows x 512 uint16) */
+int frp_gallery_get(frp_handle* h, void* out_f16, int64_t first_row, int64_t n_rows);
+
+/* ---- the hot path -----------------------------------------------------------------
+ * replaces, per frame: cv2.cvtColor(BGR2RGB) (camera.py:225), face_recognition.face_locations
+ * (camera.py:232, face_service.py:156), the max_faces cap (camera.py:233-235),
+ * face_recognition.face_encodings (camera.py:237, face_service.py:179), and per face
+ * FaceService.compare_faces + the caller's filter loop reduced to top-1
+ * (face_service.py:395-443, camera.py:243-259).
+ *
+ * bgr: B frames of H x W x 3 u8, row_stride bytes between rows, frames contiguous
+ * (frame b starts at bgr + b*H*row_stride).  Outputs (any may be NULL):
+ *   boxes  [B*K*4]  x1,y1,x2,y2 in frame pixels     kps [B*K*10]  5 x (x,y)
+ *   scores [B*K]    sigmoid of the anchor logit      counts [B]   faces kept (<= K = max_faces)
+ *   emb    [B*K*512] unit embeddings                 match_idx [B*K] gallery row of the best
+ *   match_cos [B*K] its cosine (distance = sqrt(max(0, 2-2cos)))      cosine, -1 if no gallery
+ * Slots k >= counts[b] are zero-filled (match_idx -1). */
+int frp_process_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,
+                       int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags,
+                       float* boxes, float* kps, float* scores, int32_t* counts,
+                       float* emb, int32_t* match_idx, float* match_cos);
+
+/* Same pipeline split for callers that keep frames resident in HBM (the benchmark's timed
+ * region starts with inputs already on the device): upload once, process many, fetch. */
+int frp_upload_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride);
+int frp_process_resident(frp_handle* h, int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags);
+int frp_fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts,
+                      float* emb, int32_t* match_idx, float* match_cos);
+int frp_synchronize(frp_handle* h);
+
+/* ---- stage entry points (REST paths and parity tests) ------------------------------- */
+/* detection only -> face_recognition.face_locations (camera.py:232) */
+int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,
+               int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags,
+               float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx);
+/* raw detector head maps of the last detect/process call, per stride level 0..2:
+ * [B, H/stride, W/stride, 32] fp16 (parity tests) */
+int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl);
+/* decode + NMS on caller-supplied head maps [B,H_l,W_l,32] fp16 (parity tests) */
+int frp_decode_heads(frp_handle* h, const void* head8, const void* head16, const void* head32,
+                     int32_t B, int32_t canvas_h, int32_t canvas_w, int32_t max_faces, float det_thresh, float nms_iou,
+                     uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx);
+/* 5-landmark similarity warp -> normalised chips [M,112,112,8] fp16 (channels R,G,B,0..)
+ * -> insightface norm_crop behind face_encodings (camera.py:237) */
+int frp_align(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t row_stride,
+              const float* kps, int32_t M, uint32_t flags, void* chips_f16);
+/* aligned u8 BGR chips [M,112,112,3] -> unit embeddings [M,512] */
+int frp_embed_aligned(frp_handle* h, const uint8_t* chips, int32_t M, float* emb);
+/* landmarks on one frame -> unit embeddings [M,512] (face_encodings with known faces) */
+int frp_embed_faces(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t row_stride,
+                    const float* kps, int32_t M, uint32_t flags, float* emb);
+/* cosine top-1 (topk must be 1 in this version) of M unit queries vs the gallery
+ * -> face_recognition.face_distance + argmin (face_service.py:410,599-603) */
+int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* idx, float* cos);
+/* all cosines [M x N] (the N-dict compat path of compare_faces, face_service.py:409-432) */
+int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all);
+
+/* one convolution through the MFMA kernel on host tensors (kernel parity tests):
+ * x [N,H,W,Cin] fp16, w [Cout][k][k][Cin] fp16, bias fp32 [Cout] or [9][Cout], out fp16 or fp32 */
+int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                    const void* w, int32_t Cout, int32_t ksize, int32_t stride,
+                    const float* bias, const float* slope, const void* res, int32_t res_h, int32_t res_w,
+                    int32_t act, int32_t flags, void* out);
+
+/* ---- observability ---------------------------------------------------------------
+ * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */
+int frp_get_counters(frp_handle* h, frp_counters* out);
+int frp_reset_counters(frp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRP_H */

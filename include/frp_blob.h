@@ -1,0 +1,37 @@
+/* frp_blob.h -- binary layout of the weight/program blob consumed by frp_load_weights.
+ * Little-endian.  Produced by face-recognition-platform_amd/weights.py (pack_blob).
+ * Replaces the model-pack files insightface downloads at run time
+ * (backend/app/utils/deepfake_utils.py:39-51); layer tables: netspec.py. */
+#ifndef FRP_BLOB_H
+#define FRP_BLOB_H
+#include <stdint.h>
+
+#define FRP_BLOB_MAGIC "FRPBLOB1"
+#define FRP_BLOB_VERSION 1u
+
+#pragma pack(push, 1)
+typedef struct frp_blob_header {      /* 128 bytes */
+    char magic[8];
+    uint32_t version;
+    uint32_t header_bytes;
+    uint32_t n_det_ops, n_det_bufs, det_in_buf, det_in_ch;
+    uint32_t det_head_buf[3];         /* stride 8, 16, 32 */
+    uint32_t det_num_anchors;         /* per location */
+    uint32_t n_emb_ops, n_emb_bufs, emb_in_buf, emb_in_ch;
+    uint32_t emb_out_buf, emb_size, emb_dim, reserved0;
+    uint64_t det_ops_offset, emb_ops_offset, data_offset, data_bytes;
+    uint64_t det_macs_1080p, emb_macs; /* informational */
+} frp_blob_header;
+
+typedef struct frp_conv_op {          /* 64 bytes */
+    int32_t in_buf, out_buf, res_buf; /* physical activation buffer ids; res_buf -1 = none */
+    int32_t cin, cout, ksize, stride; /* pad = ksize/2 */
+    int32_t act;                      /* 0 none, 1 ReLU, 2 PReLU */
+    int32_t flags;                    /* 1 border-class bias [9][cout], 2 fp32 output,
+                                         4 residual read at (y>>1,x>>1), 8 input viewed as 1x1x(H*W*C) */
+    int32_t real_ch;                  /* cin_real | cout_real << 16 (unpadded channel counts, for flop accounting) */
+    int64_t w_off, bias_off, slope_off; /* byte offsets into the data section; slope_off -1 = none */
+} frp_conv_op;
+#pragma pack(pop)
+
+#endif
