@@ -754,11 +754,14 @@ int frp_decode_heads(frp_handle* h, const void* head8, const void* head16, const
     return FRP_OK;
 }
 
-static int align_common(frp_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, const float* kps, int M, uint32_t flags) {
-    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+// to_embedder: chips go to the embedder's input buffer (needs weights); else to h->scratch
+static int align_common(frp_handle* h, const uint8_t* bgr, int H, int W, int64_t row_stride, const float* kps, int M, uint32_t flags,
+                        bool to_embedder) {
+    if (to_embedder && !h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
     if (!kps || M <= 0 || M > 65536) return fail(h, FRP_ERR_INVALID, "bad landmark arguments");
     FRPCHK(upload_frames(h, bgr, 1, H, W, row_stride));
-    FRPCHK(plan_net(h, h->emb, M, FRP_CHIP, FRP_CHIP));
+    if (to_embedder) FRPCHK(plan_net(h, h->emb, M, FRP_CHIP, FRP_CHIP));
+    else FRPCHK(ensure(h, h->scratch, (size_t)M * FRP_CHIP_PIX * 16));
     FRPCHK(ensure(h, h->kps, (size_t)M * 40));
     HIPCHK(h, hipMemcpyAsync(h->kps.p, kps, (size_t)M * 40, hipMemcpyHostToDevice, h->stream));
     AlignParams ap{};
@@ -770,7 +773,7 @@ static int align_common(frp_handle* h, const uint8_t* bgr, int H, int W, int64_t
     ap.face_slot = nullptr;
     ap.n_faces = M;
     ap.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
-    ap.chips = (_Float16*)h->emb.bufs[h->emb.in_buf].p;
+    ap.chips = to_embedder ? (_Float16*)h->emb.bufs[h->emb.in_buf].p : (_Float16*)h->scratch.p;
     hipError_t e = launch_align(ap, h->stream);
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("align: ") + hipGetErrorString(e));
     return FRP_OK;
@@ -781,8 +784,8 @@ int frp_align(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t r
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (!chips_f16) return fail(h, FRP_ERR_INVALID, "null output");
-    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags));
-    HIPCHK(h, hipMemcpyAsync(chips_f16, h->emb.bufs[h->emb.in_buf].p, (size_t)M * FRP_CHIP_PIX * 8 * 2, hipMemcpyDeviceToHost, h->stream));
+    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags, false));
+    HIPCHK(h, hipMemcpyAsync(chips_f16, h->scratch.p, (size_t)M * FRP_CHIP_PIX * 8 * 2, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return FRP_OK;
 }
@@ -792,7 +795,7 @@ int frp_embed_faces(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (!emb) return fail(h, FRP_ERR_INVALID, "null output");
-    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags));
+    FRPCHK(align_common(h, bgr, H, W, row_stride, kps, M, flags, true));
     FRPCHK(run_embed(h, M));
     HIPCHK(h, hipMemcpyAsync(emb, h->emb.bufs[h->hdr.emb_out_buf].p, (size_t)M * FRP_EMB_DIM * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1,0 +1,236 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import get_raw_and_blob
+from oracle import network as onet
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_ref(x, w, bias, stride, act, slope, res, flags):
+    """fp32 reference on the fp16-rounded operands.  x NHWC, w [Cout,k,k,Cin]."""
+    xt = torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w.astype(np.float32)).permute(0, 3, 1, 2)
+    k = w.shape[1]
+    y = F.conv2d(xt, wt, None, stride=stride, padding=k // 2).permute(0, 2, 3, 1).numpy()
+    N, Ho, Wo, Co = y.shape
+    if flags & 1:
+        cy = np.where(np.arange(Ho) == 0, 0, np.where(np.arange(Ho) == Ho - 1, 2, 1))
+        cx = np.where(np.arange(Wo) == 0, 0, np.where(np.arange(Wo) == Wo - 1, 2, 1))
+        cls = cy[:, None] * 3 + cx[None, :]
+        y = y + bias[cls][None]
+    else:
+        y = y + bias[None, None, None, :]
+    if res is not None:
+        r = res.astype(np.float32)
+        if flags & 4:
+            r = np.repeat(np.repeat(r, 2, axis=1), 2, axis=2)
+        y = y + r
+    if act == 1:
+        y = np.maximum(y, 0)
+    elif act == 2:
+        y = np.where(y > 0, y, y * slope[None, None, None, :])
+    return y
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, act, res, flags
+    (2, 16, 16, 64, 64, 3, 1, 1, False, 0),
+    (1, 17, 13, 64, 128, 3, 2, 0, True, 0),
+    (2, 9, 9, 128, 256, 1, 1, 2, False, 0),
+    (1, 20, 20, 8, 32, 3, 2, 1, False, 0),      # stem: small-Cin path, Ktot=72
+    (1, 12, 12, 32, 64, 3, 2, 1, False, 0),     # small-Cin path, Ktot=288
+    (3, 7, 7, 256, 512, 3, 1, 2, False, 1),     # border-class bias
+    (1, 8, 8, 128, 128, 1, 1, 0, True, 4),      # FPN lateral + 2x upsampled residual
+    (4, 1, 1, 1024, 512, 1, 1, 0, False, 2),    # FC-shaped, fp32 out
+    (1, 8, 8, 128, 32, 3, 1, 0, False, 0),      # head: Cout=32
+    (2, 14, 14, 64, 128, 1, 2, 0, False, 0),    # 1x1 stride-2 shortcut
+    (1, 5, 7, 64, 64, 3, 1, 1, True, 0),        # ragged: M=35 << tile
+    (5, 28, 28, 128, 128, 3, 1, 2, True, 1),    # multi-tile, all epilogue features
+    (1, 40, 24, 64, 64, 3, 2, 1, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_parity(engine, case):
+    N, H, W, Cin, Cout, k, stride, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float16)
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = None
+    if has_res:
+        res = rng.standard_normal((N, Ho // 2, Wo // 2, Cout) if flags & 4 else (N, Ho, Wo, Cout)).astype(np.float16)
+    out = engine.conv2d(x, w, bias, stride=stride, act=act, slope=slope, res=res, flags=flags)
+    ref = _conv_ref(x, w, bias, stride, act, slope, res, flags)
+    assert out.shape == ref.shape
+    # fp32 accumulate: error is the fp16 output rounding (rel 2^-11) + summation order
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max())) if not (flags & 2) else 1e-4 * max(1.0, float(np.abs(ref).max()))
+    err = np.abs(out.astype(np.float32) - ref).max()
+    assert err <= tol, f"max err {err} > {tol}"
+
+
+def test_conv_rejects_unsupported_shape(engine):
+    from frp_amd.native import FrpError
+    x = np.zeros((1, 8, 8, 24), np.float16)     # Cin=24: not a power of two below 64
+    w = np.zeros((32, 3, 3, 24), np.float16)
+    with pytest.raises(FrpError):
+        engine.conv2d(x, w, np.zeros(32, np.float32))
+
+
+@pytest.mark.parametrize("N,M", [(1000, 5), (128, 1), (4097, 37), (10000, 320), (1, 3)])
+def test_match_parity(engine, N, M):
+    rng = np.random.default_rng(N * 7 + M)
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    planted = rng.integers(0, N, size=M)
+    Q = G[planted] + 0.05 * rng.standard_normal((M, 512)).astype(np.float32) / np.sqrt(512) * 4
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    engine.gallery_set(G)
+    assert engine.gallery_size() == N
+    idx, cos = engine.match(Q)
+    g16 = engine.gallery_get().astype(np.float32)
+    assert np.abs(g16 - G).max() < 1e-3
+    oidx, ocos = onet.match_topk(G, Q, 1)
+    assert np.array_equal(idx, oidx[:, 0])          # identical top-1 identity
+    assert np.abs(cos - ocos[:, 0]).max() < 1e-3    # north_star: within 1e-3 cosine
+    if N <= 4097:
+        S = engine.match_scores(Q)
+        assert np.abs(S - Q.astype(np.float64) @ G.T.astype(np.float64)).max() < 1e-3
+
+
+def test_match_ties_prefer_lower_index(engine):
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal((1, 512)).astype(np.float32)
+    G = np.repeat(g, 300, axis=0)                   # all rows identical -> every score ties
+    engine.gallery_set(G)
+    idx, cos = engine.match(g)
+    assert idx[0] == 0 and abs(cos[0] - 1.0) < 1e-3
+
+
+def test_gallery_update_remove(engine):
+    rng = np.random.default_rng(11)
+    G = rng.standard_normal((10, 512)).astype(np.float32)
+    engine.gallery_set(G)
+    new = rng.standard_normal(512).astype(np.float32)
+    engine.gallery_update_row(10, new)              # append
+    assert engine.gallery_size() == 11
+    idx, cos = engine.match(new[None])
+    assert idx[0] == 10 and cos[0] > 0.999
+    engine.gallery_remove_row(3)                    # last row moves into slot 3
+    assert engine.gallery_size() == 10
+    idx, _ = engine.match(new[None])
+    assert idx[0] == 3
+    engine.gallery_update_row(0, -new)              # overwrite
+    idx, cos = engine.match(-new[None])
+    assert idx[0] == 0 and cos[0] > 0.999
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+    assert engine.gallery_size() == 0
+    from frp_amd.native import FrpError
+    with pytest.raises(FrpError):
+        engine.match(new[None])
+
+
+def _random_heads(rng, B, Hc, Wc, logit_scale=3.0, logit_shift=-4.0):
+    heads = []
+    for s in (8, 16, 32):
+        h = rng.standard_normal((B, Hc // s, Wc // s, 32)).astype(np.float32)
+        h[..., 0] = h[..., 0] * logit_scale + logit_shift
+        h[..., 15] = h[..., 15] * logit_scale + logit_shift
+        h[..., 1:5] = np.abs(h[..., 1:5]) * 2 + 0.5       # positive distances: real boxes
+        h[..., 16:20] = np.abs(h[..., 16:20]) * 2 + 0.5
+        heads.append(h.astype(np.float16))
+    return heads
+
+
+@pytest.mark.parametrize("Hc,Wc,thresh,forced,shift", [
+    (64, 96, 0.5, False, -4.0),       # few candidates
+    (320, 320, 0.5, False, -1.0),     # thousands of candidates > CAP: radix-select path, heavy NMS
+    (320, 320, 0.5, True, -4.0),      # forced top-K
+    (1088, 1920, 0.5, False, -8.0),   # full 1080p canvas: 85,680 anchors
+    (1088, 1920, 0.3, True, 0.0),
+    (64, 64, 0.999, False, -9.0),     # nothing passes
+])
+def test_decode_nms_parity(engine, Hc, Wc, thresh, forced, shift):
+    rng = np.random.default_rng(Hc * 31 + Wc + int(forced))
+    B = 2
+    heads = _random_heads(rng, B, Hc, Wc, logit_shift=shift)
+    K = 10
+    o = engine.decode_heads(heads, (Hc, Wc), max_faces=K, det_thresh=thresh, nms_iou=0.4, flags=1 if forced else 0)
+    for b in range(B):
+        ob, ok, osc, oa = onet.decode_nms([h[b] for h in heads], 0.0 if forced else thresh, 2.0 if forced else 0.4, K)
+        n = len(oa)
+        assert o["counts"][b] == n
+        assert np.array_equal(o["anchor_idx"][b, :n], oa)             # same faces, same order
+        assert np.array_equal(o["boxes"][b, :n], ob)                  # bit-exact fp32 box arithmetic
+        assert np.array_equal(o["kps"][b, :n], ok)
+        assert np.abs(o["scores"][b, :n] - osc).max() < 1e-6 if n else True
+        assert np.all(o["boxes"][b, n:] == 0) and np.all(o["anchor_idx"][b, n:] == -1)
+
+
+def test_decode_ties_by_anchor_index(engine):
+    heads = [np.zeros((1, 64 // s, 64 // s, 32), np.float16) for s in (8, 16, 32)]
+    for h in heads:
+        h[..., 0] = 2.0
+        h[..., 15] = 2.0          # every anchor has the same logit
+        h[..., 1:5] = 0.1
+        h[..., 16:20] = 0.1       # tiny boxes: no overlap between locations
+    o = engine.decode_heads(heads, (64, 64), max_faces=6, det_thresh=0.5, nms_iou=0.4)
+    ob, _, _, oa = onet.decode_nms([h[0] for h in heads], 0.5, 0.4, 6)
+    assert np.array_equal(o["anchor_idx"][0, :6], oa)
+    assert list(oa[:2]) == [0, 2]   # anchor 1 sits on anchor 0's box (IoU 1) and is suppressed
+
+
+def test_align_parity(engine):
+    rng = np.random.default_rng(5)
+    H, W = 240, 320
+    frame = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    frame = (0.5 * frame + 0.5 * np.roll(frame, 1, axis=1)).astype(np.uint8)
+    kps = []
+    for (cx, cy, sc, ang) in [(160, 120, 1.5, 0.1), (60, 50, 0.6, -0.4), (300, 220, 2.0, 0.8), (10, 10, 1.0, 0.0)]:
+        t = onet.ARCFACE_TEMPLATE - 56.0
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        kps.append((t @ R.T) * sc + [cx, cy] + rng.standard_normal((5, 2)) * 1.5)
+    kps = np.array(kps, dtype=np.float32)
+    chips = engine.align(frame, kps)                       # [M,112,112,8] fp16, RGB (x-127.5)/127.5
+    ref = onet.align_faces(frame, kps)                     # BGR float 0..255
+    ref_blob = (ref[..., ::-1] - 127.5) / 127.5
+    assert np.all(chips[..., 3:] == 0)
+    err = np.abs(chips[..., :3].astype(np.float32) - ref_blob)
+    assert err.max() < 6e-3, err.max()                     # fp16 rounding + fp32 source coordinates
+    assert err.mean() < 5e-4
+
+
+def test_embed_parity_small_and_r100(engine):
+    rng = np.random.default_rng(9)
+    chips = rng.integers(0, 256, size=(3, 112, 112, 3), dtype=np.uint8)
+    for blocks in [(1, 1, 1, 1), (3, 13, 30, 3)]:
+        raw, blob = get_raw_and_blob((1, 1, 1, 1), blocks)
+        engine.load_weights(blob)
+        e = engine.embed_aligned(chips)
+        ref = onet.emb_forward(raw, onet.emb_blob(chips))
+        assert np.abs(np.linalg.norm(e, axis=1) - 1).max() < 1e-4
+        cos = (e * ref).sum(1)
+        assert cos.min() > 1 - 1e-3, (blocks, cos)          # north_star tolerance
+
+
+def test_detector_head_maps_parity(engine):
+    rng = np.random.default_rng(21)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    frames = rng.integers(0, 256, size=(2, 150, 200, 3), dtype=np.uint8)   # canvas 160 x 224 (letterboxed)
+    engine.detect(frames, max_faces=4, det_thresh=0.5)
+    heads = engine.head_maps()
+    ref = onet.det_forward(raw, onet.det_blob(frames, (160, 224)))
+    for g, r in zip(heads, ref):
+        assert g.shape[:3] == r.shape[:3]
+        scale = max(1.0, float(np.abs(r).max()))
+        err = np.abs(g[..., :30].astype(np.float32) - r).max()
+        assert err < 2e-2 * scale, (err, scale)
+        assert np.all(g[..., 30:] == 0)
