@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: faces/sec (detect+embed+match) on 1080p frames vs a 100k-identity gallery.
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`),
+one camera stream per GPU (weak scaling, no data-path collective); the gallery shards are
+all-gathered once over RCCL at setup.  Frames are resident in HBM when the
+timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import frp_amd_loader  # noqa: E402,F401
+from frp_amd import native, netspec, weights  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_frames(B, H, W, K, seed):
+    """low-amplitude noise background (mean 110, sigma 12) + K planted face blobs."""
+    rng = np.random.default_rng(seed)
+    frames = np.empty((B, H, W, 3), dtype=np.uint8)
+    tmpl = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366], [41.5493, 92.3655], [70.7299, 92.2041]]) / 112.0
+    for b in range(B):
+        f = rng.normal(110.0, 12.0, size=(H, W, 3)).astype(np.float32)
+        r2 = np.random.default_rng(seed * 1000 + b)
+        for _ in range(K):
+            s = r2.uniform(80, 200)
+            x0, y0 = r2.uniform(0, W - s), r2.uniform(0, H - s)
+            yy, xx = np.mgrid[0:int(s), 0:int(s)]
+            m = ((xx / s - 0.5) / 0.38) ** 2 + ((yy / s - 0.5) / 0.48) ** 2 < 1.0
+            patch = f[int(y0):int(y0) + int(s), int(x0):int(x0) + int(s)]
+            patch[m] += 60.0
+            for (tx, ty) in tmpl:
+                cx, cy = int(tx * s), int(ty * s)
+                patch[max(0, cy - 3):cy + 3, max(0, cx - 3):cx + 3] -= 70.0
+        frames[b] = np.clip(f, 0, 255).astype(np.uint8)
+    return frames
+
+
+def gallery_rows(n_total, first, count, seed=42):
+    """rows [first, first+count) of default_rng(42).standard_normal((N,512)), unit-normalised.
+    Generated blockwise so every rank can produce its own shard without the whole matrix."""
+    out = np.empty((count, 512), dtype=np.float32)
+    blk = 4096
+    for b0 in range((first // blk) * blk, first + count, blk):
+        rows = np.random.default_rng([seed, b0 // blk]).standard_normal((blk, 512)).astype(np.float32)
+        lo, hi = max(b0, first), min(b0 + blk, first + count)
+        out[lo - first:hi - first] = rows[lo - b0:hi - b0]
+    out /= np.linalg.norm(out, axis=1, keepdims=True)
+    return out
+
+
+def cpu_baseline(raw, frames, K, n_gallery, sample_frames):
+    """Bounded CPU sample of the same workload on this box's host cores: the fp32 oracle
+    network (torch-CPU, all cores) + the reference's own per-face compare loop
+    (oracle/plumbing.py restating face_service.py:395-443 + camera.py:243-259, 1 thread)."""
+    import torch
+    from oracle import network as onet
+    from oracle import plumbing
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("FRP_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(cores)
+    fr = frames[:sample_frames]
+    H, W = fr.shape[1:3]
+    canvas = ((H + 31) // 32 * 32, (W + 31) // 32 * 32)
+    t0 = time.perf_counter()
+    res = onet.process_frames(raw, fr, None, canvas, score_thresh=0.0, nms_iou=2.0, max_faces=K)
+    t_net = time.perf_counter() - t0
+    n_faces = sum(len(r["emb"]) for r in res)
+    # reference plumbing at the same gallery size, timed on 2 faces and scaled
+    t_face = plumbing.time_reference_plumbing(n_gallery, 512, 2)
+    total = t_net + t_face * n_faces
+    return {"value": round(n_faces / total, 3), "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_frames}x1080p frames, {n_faces} faces: fp32 torch-CPU oracle network {t_net:.2f}s "
+                      f"({cores} threads) + reference compare_faces loop at N={n_gallery} {t_face:.3f}s/face (1 thread); "
+                      "the reference's literal dlib path is not installable offline"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--faces", type=int, default=10)
+    ap.add_argument("--gallery", type=int, default=100000)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, K, N, H, W = args.batch, args.faces, args.gallery, args.height, args.width
+    raw = weights.make_synthetic_raw(7)
+    blob = weights.pack_blob(raw)
+    eng = native.Engine(local_rank, max_batch=B, max_faces=K, max_h=H, max_w=W, profile=True)
+    eng.load_weights(blob)
+
+    # gallery: each rank owns rows [r*N/R, (r+1)*N/R); one RCCL all-gather replicates it (setup only)
+    if world > 1:
+        import torch
+        from frp_amd import dist as fdist
+        fdist.allgather_gallery_into_engine(eng, N, lambda first, cnt: gallery_rows(N, first, cnt), local_rank)
+    else:
+        eng.gallery_set(gallery_rows(N, 0, N))
+    assert eng.gallery_size() == N
+
+    frames = synth_frames(B, H, W, K, 1234 + rank)
+    eng.upload_frames(frames)          # inputs resident in HBM before the timed region
+    flags = native.FLAG_FORCED_K
+    for _ in range(args.warmup):
+        eng.process_resident(K, flags=flags)
+    eng.synchronize()
+    eng.reset_counters()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        eng.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.process_resident(K, flags=flags)
+    eng.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctr = eng.counters()
+    res = eng.fetch_results()
+    assert np.all(res["counts"] == K)
+
+    if rank == 0:
+        faces_total = world * args.steps * B * K
+        conv_ms = ctr["ms_det_conv"] + ctr["ms_emb_conv"]
+        conv_flops = ctr["det_conv_flops"] + ctr["emb_conv_flops"]
+        launches = ctr["det_conv_launches"] + ctr["emb_conv_launches"]
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "faces/sec (detect+embed+match) on 1080p @ 100k gallery",
+            "value": round(faces_total / dt, 2),
+            "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{B}x{H}x{W} BGR frames per GPU per step resident in HBM, forced K={K} faces/frame, "
+                                   f"{N}-identity fp16 gallery, FRPDet detector + ArcFace IResNet-100 fp16 (synthetic seeded weights)",
+                       "frames_per_s": round(world * args.steps * B / dt, 2),
+                       "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
+                       "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
+                       "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),
+                       "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in
+                                             ("ms_preprocess", "ms_det_conv", "ms_decode", "ms_align", "ms_emb_conv",
+                                              "ms_l2norm", "ms_match")}},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM conv, all detector+embedder launches)",
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": launches // max(1, args.steps),
+                         "avg_launch_us": round(conv_ms * 1e3 / max(1, launches), 2),
+                         "algorithmic_gflop_per_step": round(conv_flops / args.steps / 1e9, 1),
+                         "match_hbm_GBs": round(ctr["match_bytes"] / (ctr["ms_match"] * 1e-3) / 1e9, 1) if ctr["ms_match"] > 0 else None},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(raw, frames, K, N, args.cpu_frames)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

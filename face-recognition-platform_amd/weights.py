@@ -67,9 +67,16 @@ def make_synthetic_raw(seed: int = 7, det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13
         else:
             fan_in = cin * l.k * l.k
             w = r.standard_normal((cout, cin, l.k, l.k), dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
+            if l.name.endswith(".out"):
+                # detector head: widen the output spread and bias the two score logits negative so
+                # that the default 0.5 score threshold keeps a handful of anchors per frame
+                w = w * np.float32(6.0)
             raw[l.name + ".weight"] = w
             if l.conv_bias:
-                raw[l.name + ".bias"] = (r.standard_normal(cout) * 0.05).astype(np.float32)
+                b = (r.standard_normal(cout) * 0.05).astype(np.float32)
+                if l.name.endswith(".out"):
+                    b[0::ns.DET_VALUES_PER_ANCHOR] -= np.float32(2.0)
+                raw[l.name + ".bias"] = b
         if l.pre_bn:
             _bn(raw, seed, l.pre_bn, cin if l.name != "emb.fc" else 512)
         if l.post_bn:

@@ -42,33 +42,35 @@ def test_process_frames_end_to_end(engine):
     engine.load_weights(blob)
     B, H, W = 2, 192, 256
     frames = _frames(rng, B, H, W)
-    thr, _ = _threshold_with_margin(raw, frames, (H, W))
     K = 10
-    # gallery: oracle embeddings of the oracle's own faces + distractors
-    ref = onet.process_frames(raw, frames, None, (H, W), score_thresh=thr, nms_iou=0.4, max_faces=K)
-    planted = np.concatenate([r["emb"] for r in ref if len(r["emb"])])
     G = rng.standard_normal((500, 512)).astype(np.float32)
     G /= np.linalg.norm(G, axis=1, keepdims=True)
-    slots = rng.choice(500, size=len(planted), replace=False)
-    G[slots] = planted
-    engine.gallery_set(G)
-    out = engine.process_frames(frames, max_faces=K, det_thresh=float(thr), nms_iou=0.4)
-    f = 0
-    for b in range(B):
-        r = ref[b]
+    total = 0
+    for b in range(B):      # one threshold per frame (synthetic weights: score statistics differ per frame)
+        fr = frames[b:b + 1]
+        thr, _ = _threshold_with_margin(raw, fr, (H, W))
+        r = onet.process_frames(raw, fr, None, (H, W), score_thresh=thr, nms_iou=0.4, max_faces=K)[0]
         n = len(r["boxes"])
-        assert out["counts"][b] == n
+        assert n >= 2
+        # gallery: the oracle's embeddings of its own faces planted among distractors
+        slots = rng.choice(500, size=n, replace=False)
+        Gb = G.copy()
+        Gb[slots] = r["emb"]
+        engine.gallery_set(Gb)
+        out = engine.process_frames(fr, max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+        assert out["counts"][0] == n
         # same faces in the same order, boxes/landmarks within 0.5 px
-        assert np.abs(out["boxes"][b, :n] - r["boxes"]).max() < 0.5
-        assert np.abs(out["kps"][b, :n] - r["kps"]).max() < 0.5
+        assert np.abs(out["boxes"][0, :n] - r["boxes"]).max() < 0.5
+        assert np.abs(out["kps"][0, :n] - r["kps"]).max() < 0.5
+        assert np.abs(out["scores"][0, :n] - r["scores"]).max() < 2e-3
         for k in range(n):
-            cos = float((out["emb"][b, k] * r["emb"][k]).sum())
-            assert cos > 1 - 1e-3, cos
-            assert out["match_idx"][b, k] == slots[f]            # identical top-1 identity
-            assert abs(out["match_cos"][b, k] - 1.0) < 2e-3
-            f += 1
-        assert np.all(out["match_idx"][b, n:] == -1)
-    assert f == len(planted) and f >= 4
+            cos = float((out["emb"][0, k] * r["emb"][k]).sum())
+            assert cos > 1 - 1e-3, cos                          # north_star: within 1e-3 cosine
+            assert out["match_idx"][0, k] == slots[k]           # identical top-1 identity
+            assert abs(out["match_cos"][0, k] - 1.0) < 2e-3
+        assert np.all(out["match_idx"][0, n:] == -1) and np.all(out["emb"][0, n:] == 0)
+        total += n
+    assert total >= 4
 
 
 def test_forced_k_and_resident_path(engine):
