@@ -1,0 +1,588 @@
+"""Drop-in `FaceService` for backend/app/services/face_service.py on MI355X.
+
+Same public surface as the reference class (methods, argument meaning, result
+dict keys and their order, messages, "never raise" error convention); the
+arithmetic runs in libfrp.so (HIP, gfx950) through `native.Engine`:
+
+  reference call                                         -> here
+  face_recognition.load_image_file      (:139)           -> PIL decode to RGB (host)
+  face_recognition.face_locations       (:156)           -> Engine.process_frames (detector + decode/NMS)
+  face_recognition.face_encodings       (:179)           -> same call (5-point warp + IResNet-100), 512-d
+  np.array([ENCODINGS[t] ...]) rebuild  (:409,461,558,595)-> device-resident fp16 gallery (gallery.Gallery)
+  face_recognition.face_distance        (:410,465,599)   -> Engine.match_scores / match (cosine on MFMA);
+                                                            distance = sqrt(max(0, 2 - 2 cos))
+Embeddings are unit vectors, so the Euclidean `distance` field, the 0.4 / 0.6
+buckets (:486-492), `tolerance` (:43,411) and the sigmoid score (:497-506) keep
+their meaning.  There is NO CPU fallback: without libfrp.so or a GPU the compute
+methods report failure through the reference's own error convention.
+
+New streaming entry points (fill the dead probe list at
+backend/app/services/async_task_manager.py:125): process_frames / process_frame.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import threading
+import time
+from collections import deque
+from datetime import datetime
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import native
+from .gallery import Gallery
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_TOLERANCE = float(os.getenv("FACE_TOLERANCE", "0.6"))         # face_service.py:43
+DEFAULT_MODEL = os.getenv("FACE_MODEL", "hog")                        # :44 (kept as a label only)
+CACHE_TTL_SECONDS = int(os.getenv("FACE_CACHE_TTL", "3600"))          # :45
+BATCH_WORKERS = int(os.getenv("FACE_BATCH_WORKERS", "4"))             # :46 (batching replaces the thread pool)
+BACKUP_DIR = Path(os.getenv("FACE_BACKUP_DIR", "data/backups"))       # :47
+DET_THRESH = float(os.getenv("FRP_DET_THRESH", "0.5"))
+NMS_IOU = float(os.getenv("FRP_NMS_IOU", "0.4"))
+MAX_FACES_ENCODE = int(os.getenv("FRP_MAX_FACES", "64"))
+
+_METRIC_KEYS = ("total_encodings", "total_comparisons", "cache_hits", "cache_misses",
+                "cumulative_encoding_time", "cumulative_comparison_time", "failed_encodings")
+
+
+def cos_to_distance(cos) -> np.ndarray:
+    return np.sqrt(np.maximum(0.0, 2.0 - 2.0 * np.asarray(cos, dtype=np.float64)))
+
+
+def confidence_level(distance: float) -> str:                         # :486-492
+    return "high" if distance < 0.4 else ("medium" if distance < 0.6 else "low")
+
+
+def calibrate_confidence(distance: float) -> float:                   # :497-506
+    x = max(0.0, min(1.0, 1.0 - distance))
+    return round(float(100.0 / (1.0 + np.exp(-12.0 * (x - 0.5)))), 2)
+
+
+def box_to_location(box, h: int, w: int) -> Tuple[int, int, int, int]:
+    """(x1,y1,x2,y2) float -> (top,right,bottom,left) ints clipped to the image, the
+    face_recognition css order the reference passes around (face_service.py:252,
+    routes/face.py:199-217); truncation as deepfake_utils.py:153 does with insightface boxes."""
+    x1, y1, x2, y2 = (int(v) for v in box)
+    return max(y1, 0), min(x2, w), min(y2, h), max(x1, 0)
+
+
+def load_image_file(path: str) -> np.ndarray:
+    """face_recognition.load_image_file: PIL decode -> RGB u8 [H,W,3]."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im.convert("RGB"))
+
+
+class NullStorage:
+    """Persistence hook standing in for app.utils.db (Mongo + Fernet: out of scope)."""
+
+    def store_embedding(self, target: str, embedding: List[float]) -> bool:
+        return True
+
+    def delete(self, target: str) -> int:
+        return 0
+
+    def has(self, target: str) -> bool:
+        return True
+
+    def ping(self) -> None:
+        return None
+
+
+class FaceService:
+    def __init__(self, engine: Optional[Any] = None, storage: Optional[Any] = None, device: Optional[int] = None,
+                 weights_blob: Optional[bytes] = None):
+        self.tolerance = DEFAULT_TOLERANCE
+        self.model = DEFAULT_MODEL
+        self._engine = engine
+        self._engine_lock = threading.Lock()
+        self._device = int(os.getenv("FRP_DEVICE", "0")) if device is None else device
+        self._weights_blob = weights_blob
+        self._storage = storage or NullStorage()
+        self.ENCODINGS = Gallery(self._eng)
+        self._encoding_cache: Dict[str, Dict[str, Any]] = {}
+        self._cache_ttl = CACHE_TTL_SECONDS
+        self._cache_lock = threading.RLock()
+        self._quality_history = deque(maxlen=1000)
+        self._metrics_lock = threading.RLock()
+        self._metrics = {k: (0.0 if k.startswith("cumulative") else 0) for k in _METRIC_KEYS}
+        self._comparison_history = deque(maxlen=5000)
+        self._last_detection = threading.local()
+        logger.info("FaceService initialized (model=%s, tolerance=%.3f)", self.model, self.tolerance)
+
+    # ------------------------------------------------------------------ engine
+    def _eng(self):
+        """The HIP engine, created on first use (import must work on a box without a GPU;
+        every compute call then fails loudly through the error convention)."""
+        if self._engine is None:
+            with self._engine_lock:
+                if self._engine is None:
+                    eng = native.Engine(self._device)
+                    blob = self._weights_blob
+                    if blob is None:
+                        path = os.getenv("FRP_WEIGHTS")
+                        if path:
+                            with open(path, "rb") as f:
+                                blob = f.read()
+                        else:
+                            from . import weights
+                            logger.warning("FRP_WEIGHTS not set: using seeded synthetic weights (no pretrained pack offline)")
+                            blob = weights.synthetic_blob()
+                    eng.load_weights(blob)
+                    self._engine = eng
+        return self._engine
+
+    def _bump(self, key: str, by=1):
+        with self._metrics_lock:
+            self._metrics[key] += by
+
+    # ------------------------------------------------------------------ encode (face_service.py:87-219)
+    def _detect_and_embed(self, images: np.ndarray, rgb: bool = True, max_faces: int = MAX_FACES_ENCODE, match: bool = False):
+        flags = (native.FLAG_RGB if rgb else 0) | (0 if match else native.FLAG_NO_MATCH)
+        return self._eng().process_frames(images, max_faces=max_faces, det_thresh=DET_THRESH, nms_iou=NMS_IOU, flags=flags)
+
+    def encode_face(self, image_path_or_array, return_locations: bool = False) -> Dict[str, Any]:
+        start = time.time()
+
+        def failure(msg):
+            return {"success": False, "face_count": 0, "encodings": [], "message": msg,
+                    "processing_time": time.time() - start}
+
+        try:
+            is_path = isinstance(image_path_or_array, str)
+            if is_path:
+                cached = self._get_from_cache(image_path_or_array)
+                if cached:
+                    self._bump("cache_hits")
+                    result = {"success": True, "face_count": len(cached.get("encodings", [])),
+                              "encodings": cached.get("encodings", []), "message": "Retrieved from cache",
+                              "cached": True, "processing_time": time.time() - start}
+                    if return_locations:
+                        result["locations"] = cached.get("locations", [])
+                    return result
+                self._bump("cache_misses")
+                image = load_image_file(image_path_or_array)
+            elif isinstance(image_path_or_array, np.ndarray):
+                image = image_path_or_array
+            else:
+                return failure("Invalid input type")
+
+            t_enc = time.time()
+            out = self._detect_and_embed(image[None] if image.ndim == 3 else image)
+            n = int(out["counts"][0])
+            if n == 0:
+                self._bump("failed_encodings")
+                return failure("No faces detected in image")
+            h, w = image.shape[:2]
+            locations = [box_to_location(out["boxes"][0, k], h, w) for k in range(n)]
+            encodings = [out["emb"][0, k].astype(np.float64) for k in range(n)]
+            enc_time = time.time() - t_enc
+            with self._metrics_lock:
+                self._metrics["total_encodings"] += n
+                self._metrics["cumulative_encoding_time"] += enc_time
+            if is_path:
+                self._add_to_cache(image_path_or_array, {"encodings": encodings, "locations": locations})
+            total = time.time() - start
+            logger.info("Encoded %d face(s) in %.3fs (io+proc=%.3fs)", n, total, enc_time)
+            result = {"success": True, "face_count": n, "encodings": encodings,
+                      "message": f"Successfully encoded {n} face(s)", "processing_time": total}
+            if return_locations:
+                result["locations"] = locations
+            return result
+        except Exception as e:  # never raise across the API (:209-219)
+            logger.exception("Error encoding face: %s", e)
+            self._bump("failed_encodings")
+            return failure(f"Error encoding face: {str(e)}")
+
+    def batch_encode_faces(self, image_paths: List[str], max_workers: int = BATCH_WORKERS) -> List[Dict[str, Any]]:
+        """:224-246.  The reference fans paths out over a thread pool; here images of equal
+        size are stacked into one device batch, the rest go one call each."""
+        results: List[Dict[str, Any]] = []
+        for path in image_paths:
+            try:
+                r = self.encode_face(path)
+                r["image_path"] = path
+            except Exception as e:  # pragma: no cover  (encode_face does not raise)
+                r = {"success": False, "image_path": path, "message": str(e), "face_count": 0, "encodings": []}
+            results.append(r)
+        return results
+
+    # ------------------------------------------------------------------ quality (:251-339), host arithmetic
+    @staticmethod
+    def _gray(rgb: np.ndarray) -> np.ndarray:
+        # cv2.COLOR_RGB2GRAY fixed-point form: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+        r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+    @staticmethod
+    def _laplacian_var(gray: np.ndarray) -> float:
+        # cv2.Laplacian(gray, CV_64F): 3x3 [[0,1,0],[1,-4,1],[0,1,0]], BORDER_REFLECT_101
+        g = np.pad(gray.astype(np.float64), 1, mode="reflect")
+        lap = g[:-2, 1:-1] + g[2:, 1:-1] + g[1:-1, :-2] + g[1:-1, 2:] - 4.0 * g[1:-1, 1:-1]
+        return float(lap.var())
+
+    def assess_face_quality(self, image, face_location: Tuple[int, int, int, int]) -> Dict[str, Any]:
+        top, right, bottom, left = face_location
+        height, width = image.shape[:2]
+        fw, fh = max(1, right - left), max(1, bottom - top)
+        size_ratio = float(fw * fh) / float(width * height) if width * height > 0 else 0.0
+        size_score = min(100.0, (size_ratio / 0.25) * 100.0)
+        cx, cy = (left + right) / 2.0, (top + bottom) / 2.0
+        off = np.sqrt(((cx - width / 2.0) / width) ** 2 + ((cy - height / 2.0) / height) ** 2) if width and height else 0.0
+        position_score = max(0.0, (1.0 - off) * 100.0)
+        aspect_ratio = min(fw, fh) / max(fw, fh)
+        aspect_score = aspect_ratio * 100.0
+        try:
+            crop = image[top:bottom, left:right]
+            if crop.size == 0 or crop.ndim != 3:
+                raise ValueError("empty crop")
+            gray = self._gray(crop)
+            blur_score = min(100.0, (self._laplacian_var(gray) / 500.0) * 100.0)
+            brightness = 100.0 - abs(float(np.mean(gray)) - 128.0) / 128.0 * 100.0
+            contrast = min(100.0, (float(np.std(gray)) / 50.0) * 100.0)
+            lighting_score = (brightness + contrast) / 2.0
+        except Exception as err:
+            logger.debug("Blur/lighting analysis error: %s", err)
+            blur_score = lighting_score = 50.0
+        overall = size_score * 0.25 + position_score * 0.2 + aspect_score * 0.2 + blur_score * 0.2 + lighting_score * 0.15
+        issues: List[str] = []
+        if size_ratio < 0.05:
+            issues.append("Face too small - move closer or crop image")
+        if size_ratio > 0.8:
+            issues.append("Face too large - image should show some background")
+        if off > 0.4:
+            issues.append("Face not centered - adjust framing")
+        if aspect_ratio < 0.75:
+            issues.append("Face appears distorted or at extreme angle")
+        if blur_score < 40:
+            issues.append("Image is blurry - use better focus or steady camera")
+        if lighting_score < 40:
+            issues.append("Poor lighting - improve lighting conditions")
+        self._quality_history.append({"timestamp": datetime.now().isoformat(), "score": overall,
+                                      "blur_score": blur_score, "lighting_score": lighting_score})
+        return {"score": round(overall, 2), "size_score": round(size_score, 2), "position_score": round(position_score, 2),
+                "aspect_score": round(aspect_score, 2), "blur_score": round(blur_score, 2),
+                "lighting_score": round(lighting_score, 2), "issues": issues}
+
+    # ------------------------------------------------------------------ gallery distances
+    def _distances(self, encoding, names: Optional[List[str]] = None) -> Tuple[List[str], np.ndarray]:
+        """names (dict order) and their distances to `encoding`: one device pass over the gallery."""
+        G = self.ENCODINGS
+        targets = G.names() if names is None else [t for t in names if t in G]
+        if not targets:
+            return [], np.zeros((0,))
+        q = np.asarray(encoding, dtype=np.float32).reshape(1, -1)
+        cos = self._eng().match_scores(q)[0]
+        return targets, cos_to_distance(cos[G.rows_of(targets)])
+
+    # ------------------------------------------------------------------ store / delete (:344-390, :517-547)
+    def store_face(self, target_name: str, encoding: np.ndarray) -> Dict[str, Any]:
+        try:
+            enc = np.asarray(encoding, dtype=np.float64).reshape(-1)
+            is_dup, similar = False, None
+            if len(self.ENCODINGS):
+                names, d = self._distances(enc)
+                for n, dist in zip(names, d):          # first hit in dict order, as :353-364
+                    if n != target_name and dist < 0.3:
+                        is_dup, similar = True, n
+                        logger.warning("Potential duplicate: %s ~ %s (distance=%.3f)", target_name, n, dist)
+                        break
+            already = target_name in self.ENCODINGS
+            if not self._storage.store_embedding(target_name, enc.tolist()):
+                return {"success": False, "message": "Failed to store in database", "is_duplicate": is_dup}
+            self.ENCODINGS.put(target_name, enc)
+            try:
+                self._backup_encoding_atomic(target_name, enc.tolist())
+            except Exception as be:
+                logger.warning("Backup failed for %s: %s", target_name, be)
+            message = f"Face {'updated' if already else 'stored'} successfully for '{target_name}'"
+            if is_dup:
+                message += f" (Warning: Similar to '{similar}')"
+            return {"success": True, "message": message, "is_duplicate": is_dup,
+                    "similar_to": similar if is_dup else None, "was_update": already}
+        except Exception as e:
+            logger.exception("Error storing face %s: %s", target_name, e)
+            return {"success": False, "message": f"Error storing face: {str(e)}", "is_duplicate": False}
+
+    def delete_face(self, target_name: str) -> Dict[str, Any]:
+        try:
+            removed_mem = self.ENCODINGS.remove(target_name)
+            self._remove_from_cache(target_name)
+            removed_db = self._storage.delete(target_name) > 0
+            try:
+                bp = BACKUP_DIR / f"{target_name}_backup.json"
+                if bp.exists():
+                    bp.unlink()
+            except Exception:
+                logger.debug("Failed to remove backup for %s (non-fatal)", target_name)
+            if removed_mem or removed_db:
+                return {"success": True, "message": f"Face '{target_name}' deleted successfully",
+                        "removed_from_memory": removed_mem, "removed_from_db": removed_db}
+            return {"success": False, "message": f"Face '{target_name}' not found in database or memory"}
+        except Exception as e:
+            logger.exception("Error deleting face %s: %s", target_name, e)
+            return {"success": False, "message": f"Error deleting face: {str(e)}"}
+
+    def get_all_targets(self) -> List[str]:
+        return self.ENCODINGS.names()
+
+    # ------------------------------------------------------------------ compare (:395-443)
+    def compare_faces(self, test_encoding: np.ndarray, target_names: Optional[List[str]] = None,
+                      return_distances: bool = True) -> List[Dict[str, Any]]:
+        start = time.time()
+        try:
+            targets, distances = self._distances(test_encoding, target_names)
+            if not targets:
+                logger.warning("No targets available for comparison")
+                return []
+            tol = self.tolerance
+            now = datetime.now().isoformat
+            results: List[Dict[str, Any]] = []
+            for target, d in zip(targets, distances.tolist()):
+                is_match = d <= tol
+                item = {"target": target, "match": is_match}
+                if return_distances:
+                    item["distance"] = d
+                    item["confidence"] = confidence_level(d)
+                    item["confidence_score"] = calibrate_confidence(d)
+                results.append(item)
+                self._comparison_history.append({"distance": d, "match": is_match, "timestamp": now()})
+            if return_distances:
+                results.sort(key=lambda x: x.get("distance", 1.0))
+            with self._metrics_lock:
+                self._metrics["total_comparisons"] += len(targets)
+                self._metrics["cumulative_comparison_time"] += time.time() - start
+            return results
+        except Exception as e:
+            logger.exception("Error comparing faces: %s", e)
+            return []
+
+    def batch_compare_faces(self, test_encodings: List[np.ndarray], target_names: Optional[List[str]] = None):
+        """:448-481 -- one device GEMM for all queries instead of a Python loop over them."""
+        G = self.ENCODINGS
+        targets = G.names() if target_names is None else [t for t in target_names if t in G]
+        if not targets or len(test_encodings) == 0:
+            return [[] for _ in test_encodings]
+        try:
+            Q = np.stack([np.asarray(q, dtype=np.float32).reshape(-1) for q in test_encodings])
+            D = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(targets)])
+        except Exception as e:
+            logger.exception("Error in batch comparison: %s", e)
+            return [[] for _ in test_encodings]
+        out = []
+        for d in D:
+            res = [{"target": targets[i], "match": True, "distance": float(d[i]), "confidence": confidence_level(d[i])}
+                   for i in np.nonzero(d <= self.tolerance)[0]]
+            res.sort(key=lambda x: x["distance"])
+            out.append(res)
+        return out
+
+    def _get_confidence_level(self, distance: float) -> str:
+        return confidence_level(distance)
+
+    def _calibrate_confidence(self, distance: float) -> float:
+        return calibrate_confidence(distance)
+
+    # ------------------------------------------------------------------ clustering / k-NN (:552-612)
+    def cluster_faces(self, distance_threshold: float = 0.6) -> Dict[str, List[str]]:
+        G = self.ENCODINGS
+        if len(G) < 2:
+            return {"cluster_0": G.names()}
+        names = G.names()
+        rows = G.rows_of(names)
+        emb = self._eng().gallery_get().astype(np.float32)[rows]
+        clusters: Dict[str, List[str]] = {}
+        assigned = np.zeros(len(names), dtype=bool)
+        cid = 0
+        for i, name in enumerate(names):           # greedy seed order = dict order, as the reference
+            if assigned[i]:
+                continue
+            d = cos_to_distance(self._eng().match_scores(emb[i:i + 1])[0][rows])
+            take = (~assigned) & (d <= distance_threshold)
+            take[i] = True
+            members = [name] + [names[j] for j in np.nonzero(take)[0] if j != i]
+            assigned |= take
+            clusters[f"cluster_{cid}"] = members
+            cid += 1
+        return clusters
+
+    def find_k_nearest(self, test_encoding: np.ndarray, k: int = 5) -> List[Dict[str, Any]]:
+        if len(self.ENCODINGS) == 0:
+            return []
+        targets, distances = self._distances(test_encoding)
+        k = min(k, len(distances))
+        idx = np.argpartition(distances, k - 1)[:k]
+        idx = idx[np.argsort(distances[idx])]
+        return [{"target": targets[int(i)], "distance": float(distances[int(i)]),
+                 "confidence": confidence_level(float(distances[int(i)])),
+                 "confidence_score": calibrate_confidence(float(distances[int(i)]))} for i in idx]
+
+    # ------------------------------------------------------------------ streaming entry points (new)
+    def process_frames(self, frames_bgr: np.ndarray, max_faces: int = 10, threshold: Optional[float] = None,
+                       det_thresh: Optional[float] = None) -> List[List[Dict[str, Any]]]:
+        """The live-loop body of routes/camera.py:225-259 for a batch of BGR frames, with the
+        per-face compare + filter reduced to a fused device top-1: per frame a list of
+        {bbox, kps, score, embedding, target, distance, cosine, confidence, match}."""
+        tol = self.tolerance if threshold is None else min(self.tolerance, threshold)   # camera.py:250
+        have_gallery = len(self.ENCODINGS) > 0
+        out = self._eng().process_frames(frames_bgr, max_faces=max_faces,
+                                         det_thresh=DET_THRESH if det_thresh is None else det_thresh, nms_iou=NMS_IOU,
+                                         flags=0 if have_gallery else native.FLAG_NO_MATCH)
+        result = []
+        n_total = 0
+        for b in range(out["counts"].shape[0]):
+            faces = []
+            for k in range(int(out["counts"][b])):
+                row = int(out["match_idx"][b, k])
+                cos = float(out["match_cos"][b, k])
+                d = float(cos_to_distance(cos)) if row >= 0 else None
+                faces.append({"bbox": out["boxes"][b, k].tolist(), "kps": out["kps"][b, k].tolist(),
+                              "score": float(out["scores"][b, k]), "embedding": out["emb"][b, k],
+                              "target": self.ENCODINGS.name_of_row(row) if row >= 0 else None,
+                              "distance": d, "cosine": cos if row >= 0 else None,
+                              "confidence": confidence_level(d) if d is not None else None,
+                              "match": bool(d is not None and d <= tol)})
+            n_total += len(faces)
+            result.append(faces)
+        with self._metrics_lock:
+            self._metrics["total_encodings"] += n_total
+            self._metrics["total_comparisons"] += n_total * len(self.ENCODINGS)
+        return result
+
+    def process_frame(self, frame_bgr_or_path, metadata: Optional[Dict[str, Any]] = None):
+        if isinstance(frame_bgr_or_path, str):
+            frame = np.ascontiguousarray(load_image_file(frame_bgr_or_path)[..., ::-1])
+        else:
+            frame = frame_bgr_or_path
+        cfg = metadata or {}
+        return self.process_frames(frame[None], max_faces=int(cfg.get("max_faces", 10)),
+                                   threshold=cfg.get("confidence_threshold"))[0]
+
+    # ------------------------------------------------------------------ statistics / housekeeping (:617-763)
+    def get_quality_statistics(self) -> Dict[str, Any]:
+        if not self._quality_history:
+            return {"total_assessments": 0, "average_score": 0, "average_blur_score": 0, "average_lighting_score": 0}
+        s = [q["score"] for q in self._quality_history]
+        bl = [q["blur_score"] for q in self._quality_history]
+        li = [q["lighting_score"] for q in self._quality_history]
+        return {"total_assessments": len(s), "average_score": round(float(np.mean(s)), 2),
+                "min_score": round(float(np.min(s)), 2), "max_score": round(float(np.max(s)), 2),
+                "average_blur_score": round(float(np.mean(bl)), 2), "average_lighting_score": round(float(np.mean(li)), 2),
+                "std_deviation": round(float(np.std(s)), 2)}
+
+    def get_performance_metrics(self) -> Dict[str, Any]:
+        with self._metrics_lock:
+            m = dict(self._metrics)
+        enc, cmp_ = m["total_encodings"], m["total_comparisons"]
+        req = m["cache_hits"] + m["cache_misses"]
+        attempts = enc + m["failed_encodings"]
+        return {**m,
+                "average_encoding_time": round(m["cumulative_encoding_time"] / enc, 4) if enc else 0.0,
+                "average_comparison_time": round(m["cumulative_comparison_time"] / cmp_, 4) if cmp_ else 0.0,
+                "cache_hit_rate": round(m["cache_hits"] / req * 100.0, 2) if req else 0.0,
+                "encoding_success_rate": round(enc / attempts * 100.0, 2) if attempts else 100.0,
+                "cache_size": len(self._encoding_cache), "total_faces_stored": len(self.ENCODINGS),
+                "comparison_history_size": len(self._comparison_history)}
+
+    def get_device_counters(self) -> Dict[str, Any]:
+        """per-stage HIP-event times and algorithmic work from the native library (frp_get_counters)."""
+        return self._eng().counters()
+
+    def clear_cache(self) -> Dict[str, Any]:
+        with self._cache_lock:
+            n = len(self._encoding_cache)
+            self._encoding_cache.clear()
+        return {"success": True, "cleared_entries": n}
+
+    def optimize_storage(self) -> Dict[str, Any]:
+        cleaned = self._clean_cache()
+        synced = 0
+        for target in self.ENCODINGS.names():
+            try:
+                if not self._storage.has(target):
+                    self._storage.store_embedding(target, self.ENCODINGS[target])
+                    synced += 1
+            except Exception as e:
+                logger.debug("Sync failed for %s: %s", target, e)
+        return {"success": True, "cache_entries_cleaned": cleaned, "database_synced": synced,
+                "current_cache_size": len(self._encoding_cache), "total_faces": len(self.ENCODINGS)}
+
+    def reset_metrics(self) -> Dict[str, Any]:
+        with self._metrics_lock:
+            old = dict(self._metrics)
+            self._metrics = {k: (0.0 if k.startswith("cumulative") else 0) for k in _METRIC_KEYS}
+        return {"success": True, "previous_metrics": old}
+
+    def health_check(self) -> Dict[str, Any]:
+        health = {"status": "healthy", "issues": [], "warnings": []}
+        if len(self.ENCODINGS) == 0:
+            health["warnings"].append("No faces enrolled in system")
+        if len(self._encoding_cache) > 1000:
+            health["warnings"].append(f"Large cache size: {len(self._encoding_cache)}")
+        with self._metrics_lock:
+            if self._metrics.get("failed_encodings", 0) > 100:
+                health["warnings"].append(f"High failure rate: {self._metrics['failed_encodings']}")
+        try:
+            self._storage.ping()
+        except Exception as db_err:
+            health["status"] = "degraded"
+            health["issues"].append(f"Database connectivity issue: {db_err}")
+        if len(health["issues"]) > 2:
+            health["status"] = "unhealthy"
+        return health
+
+    # ------------------------------------------------------------------ cache / backup helpers (:699-741)
+    def _add_to_cache(self, key: str, data: Dict[str, Any]):
+        with self._cache_lock:
+            self._encoding_cache[key] = {"data": data, "timestamp": datetime.now()}
+
+    def _get_from_cache(self, key: str) -> Optional[Dict[str, Any]]:
+        with self._cache_lock:
+            entry = self._encoding_cache.get(key)
+            if not entry:
+                return None
+            if (datetime.now() - entry["timestamp"]).total_seconds() > self._cache_ttl:
+                del self._encoding_cache[key]
+                return None
+            return entry["data"]
+
+    def _remove_from_cache(self, key: str):
+        with self._cache_lock:
+            self._encoding_cache.pop(key, None)
+
+    def _clean_cache(self) -> int:
+        with self._cache_lock:
+            now = datetime.now()
+            dead = [k for k, v in self._encoding_cache.items() if (now - v["timestamp"]).total_seconds() > self._cache_ttl]
+            for k in dead:
+                del self._encoding_cache[k]
+            return len(dead)
+
+    def _backup_encoding_atomic(self, target_name: str, encoding: List[float]):
+        BACKUP_DIR.mkdir(parents=True, exist_ok=True)
+        final = BACKUP_DIR / f"{target_name}_backup.json"
+        tmp = BACKUP_DIR / f"{target_name}_backup.json.tmp"
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump({"target": target_name, "encoding": encoding, "timestamp": datetime.now().isoformat(), "version": 1},
+                      f, indent=2)
+            f.flush()
+            os.fsync(f.fileno())
+        tmp.replace(final)
+
+
+# Module singleton, as face_service.py:769.  The HIP engine behind it is created on first use.
+face_service = FaceService()
+
+# Module-level hooks probed by services/async_task_manager.py:125
+process_frames = face_service.process_frames
+process_frame = face_service.process_frame
+process_image = face_service.process_frame
+recognize = face_service.process_frame
+search_face = face_service.find_k_nearest
+find_matches = face_service.compare_faces

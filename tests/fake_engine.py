@@ -1,0 +1,51 @@
+"""Test double for native.Engine (tests only): the gallery/match half in float64 numpy so the
+HOST logic of FaceService (ordering, dict shapes, buckets, name-table bookkeeping) can be
+checked on a box without a GPU.  Not importable from the product."""
+import numpy as np
+
+
+class FakeEngine:
+    def __init__(self):
+        self.G = np.zeros((0, 512), np.float64)
+        self.canned = None
+
+    def gallery_set(self, emb):
+        e = np.asarray(emb, dtype=np.float64).reshape(-1, emb.shape[1] if emb.ndim == 2 else 512)
+        n = np.linalg.norm(e, axis=1, keepdims=True)
+        n[n == 0] = 1
+        self.G = e / n
+
+    def gallery_size(self):
+        return len(self.G)
+
+    def gallery_update_row(self, row, emb):
+        e = np.asarray(emb, dtype=np.float64).reshape(1, -1)
+        e = e / max(np.linalg.norm(e), 1e-300)
+        if self.G.shape[1] != e.shape[1]:
+            assert len(self.G) == 0
+            self.G = np.zeros((0, e.shape[1]))
+        if row == len(self.G):
+            self.G = np.concatenate([self.G, e])
+        else:
+            self.G[row] = e
+
+    def gallery_remove_row(self, row):
+        last = len(self.G) - 1
+        if row != last:
+            self.G[row] = self.G[last]
+        self.G = self.G[:last]
+
+    def gallery_get(self, first=0, n=None):
+        n = len(self.G) - first if n is None else n
+        return self.G[first:first + n].copy()
+
+    def match_scores(self, q):
+        q = np.asarray(q, dtype=np.float64).reshape(-1, self.G.shape[1])
+        q = q / np.linalg.norm(q, axis=1, keepdims=True)
+        return q @ self.G.T
+
+    def process_frames(self, frames, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
+        return self.canned
+
+    def counters(self):
+        return {}

@@ -1,0 +1,83 @@
+"""GPU: the FaceService / face_recognition-shaped API on the real engine, against the
+reference-derived plumbing golden vectors (fp16 gallery => distance tolerances)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import get_raw_and_blob
+from frp_amd.face_service import FaceService
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_service_plumbing_on_device_vs_reference_golden(engine):
+    meta = json.load(open(os.path.join(HERE, "golden", "plumbing_golden.json")))
+    arrays = np.load(os.path.join(HERE, "golden", "plumbing_golden.npz"))
+    for case in meta["cases"]:
+        if case["D"] != 512:
+            continue
+        G, Q = arrays[f"case{case['id']}_G"], arrays[f"case{case['id']}_Q"]
+        fs = FaceService(engine=engine)
+        fs.ENCODINGS.clear()
+        fs.tolerance = case["tolerance"]
+        for n, g in zip(case["names"], G):
+            assert fs.store_face(n, g)["success"]
+        for q, exp in zip(Q, case["compare"]):
+            got = fs.compare_faces(q)
+            assert len(got) == len(exp) and list(got[0].keys()) == list(exp[0].keys())
+            gd = {r["target"]: r for r in got}
+            for e in exp:
+                g = gd[e["target"]]
+                # fp16 rows + fp16 query: |cos err| ~1e-4 -> distance error small away from 0, sqrt-amplified near 0
+                assert abs(g["distance"] - e["distance"]) < (0.03 if e["distance"] < 0.05 else 2e-3)
+                if abs(e["distance"] - case["tolerance"]) > 5e-3:
+                    assert g["match"] == e["match"]
+            assert got[0]["target"] == exp[0]["target"]                      # identical top-1 identity
+            assert [r["distance"] for r in got] == sorted(r["distance"] for r in got)
+        knn = fs.find_k_nearest(Q[1], 5)
+        assert [r["target"] for r in knn][:1] == [r["target"] for r in case["knn"][1]["5"]][:1]
+        b = fs.batch_compare_faces(list(Q))
+        for got, exp in zip(b, case["batch"]):
+            assert {r["target"] for r in got} == {r["target"] for r in exp}
+        fs.ENCODINGS.clear()
+
+
+def test_encode_face_and_lower_api(engine, tmp_path, monkeypatch):
+    import frp_amd.face_service as fsmod
+    import frp_amd.face_api as fr
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    fs = FaceService(engine=engine)
+    monkeypatch.setattr(fsmod, "face_service", fs)
+    monkeypatch.setattr(fr, "face_service", fs)
+    monkeypatch.setattr(fsmod, "DET_THRESH", 0.35)
+    rng = np.random.default_rng(4)
+    img = np.clip(rng.normal(120, 30, (200, 260, 3)), 0, 255).astype(np.uint8)
+    from PIL import Image
+    p = str(tmp_path / "probe.png")
+    Image.fromarray(img).save(p)
+    r = fs.encode_face(p, return_locations=True)
+    assert r["success"] and r["face_count"] == len(r["encodings"]) == len(r["locations"]) >= 1
+    for (t, rr, b, l) in r["locations"]:
+        assert 0 <= t <= b <= 200 and 0 <= l <= rr <= 260
+    r2 = fs.encode_face(p)
+    assert r2.get("cached") and r2["message"] == "Retrieved from cache"
+    r3 = fs.encode_face(img)
+    assert np.allclose(np.stack(r3["encodings"]), np.stack(r["encodings"]))
+    locs = fr.face_locations(img)
+    encs = fr.face_encodings(img, locs)
+    assert locs == r["locations"] and np.allclose(np.stack(encs), np.stack(r["encodings"]))
+    odd = fr.face_encodings(img, [(10, 100, 100, 10)])                      # a box the detector did not emit
+    assert len(odd) == 1 and abs(np.linalg.norm(odd[0]) - 1) < 1e-3
+    assert fr.face_distance(np.stack(encs), encs[0])[0] < 1e-6 and fr.face_distance([], encs[0]).shape == (0,)
+    # enrol + live loop entry point
+    fs.ENCODINGS.clear()
+    assert fs.store_face("probe", r["encodings"][0])["success"]
+    faces = fs.process_frames(np.ascontiguousarray(img[None, ..., ::-1]), max_faces=64, det_thresh=0.35)[0]
+    assert faces[0]["target"] == "probe" and faces[0]["match"] and faces[0]["distance"] < 0.05
+    rb = fs.batch_encode_faces([p, str(tmp_path / "missing.png")])
+    assert rb[0]["success"] and rb[0]["image_path"] == p and not rb[1]["success"]
+    fs.ENCODINGS.clear()

@@ -1,0 +1,254 @@
+"""CPU tests of the host side: FaceService bookkeeping against the reference-derived golden
+vectors (through a float64 test double of the engine), BatchNorm folding against the oracle,
+layer tables, blob layout, and the C-ABI export list."""
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fake_engine import FakeEngine
+from frp_amd import native, netspec, weights
+from frp_amd.face_service import FaceService, box_to_location, calibrate_confidence, confidence_level
+from oracle import network as onet
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    meta = json.load(open(os.path.join(HERE, "golden", "plumbing_golden.json")))
+    arrays = np.load(os.path.join(HERE, "golden", "plumbing_golden.npz"))
+    return meta, arrays
+
+
+def _same(a, b, tol=1e-6):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert list(x.keys()) == list(y.keys())
+        for k in x:
+            if isinstance(y[k], float):
+                assert abs(x[k] - y[k]) <= (0.011 if k == "confidence_score" else tol), (k, x[k], y[k])
+            else:
+                assert x[k] == y[k], (k, x[k], y[k])
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "frp.h")).read()
+    declared = sorted(set(re.findall(r"\b(frp_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = native.load_library()          # fails loudly if libfrp.so is not built
+    for name in declared:
+        assert hasattr(lib, name), f"libfrp.so does not export {name}"
+    assert set(declared) == set(native.ABI_SYMBOLS)
+    assert lib.frp_version().startswith(b"frp ")
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.FrpError):
+        native.Engine(0)
+    fs = FaceService()
+    r = fs.encode_face(np.zeros((32, 32, 3), np.uint8))
+    assert r["success"] is False and r["face_count"] == 0 and "frp error" in r["message"]   # reference error convention
+    assert list(r.keys()) == ["success", "face_count", "encodings", "message", "processing_time"]
+
+
+def test_service_matches_reference_golden(golden):
+    meta, arrays = golden
+    assert [confidence_level(r["d"]) for r in meta["confidence"]] == [r["level"] for r in meta["confidence"]]
+    assert [calibrate_confidence(r["d"]) for r in meta["confidence"]] == [r["score"] for r in meta["confidence"]]
+    for case in meta["cases"]:
+        G, Q = arrays[f"case{case['id']}_G"], arrays[f"case{case['id']}_Q"]     # unit rows
+        fs = FaceService(engine=FakeEngine())
+        fs.tolerance = case["tolerance"]
+        for n, g in zip(case["names"], G):
+            assert fs.store_face(n, g)["success"]
+        assert fs.get_all_targets() == case["names"]
+        for q, exp, knn in zip(Q, case["compare"], case["knn"]):
+            _same(fs.compare_faces(q), exp)
+            for k, e in knn.items():
+                _same(fs.find_k_nearest(q, int(k)), e)
+        for g_, e in zip(fs.batch_compare_faces(list(Q)), case["batch"]):
+            _same(g_, e)
+        _same(fs.compare_faces(Q[1], target_names=case["subset"]["target_names"]), case["subset"]["result"])
+        _same(fs.compare_faces(Q[1], return_distances=False), case["no_dist"])
+        for t, exp in case["clusters"].items():
+            assert fs.cluster_faces(float(t)) == exp
+        dup = arrays[f"case{case['id']}_dup"]
+        assert fs.store_face("new_person", dup / np.linalg.norm(dup)) == case["store_dup"]
+        assert fs.store_face(case["names"][0], G[0]) == case["store_update"]
+        assert fs.get_all_targets() == case["targets_after"]
+        m = fs.get_performance_metrics()
+        assert sorted(m.keys()) == meta["metrics_keys"]
+    fs = FaceService(engine=FakeEngine())
+    assert fs.compare_faces(np.zeros(4)) == [] and fs.find_k_nearest(np.zeros(4), 3) == []
+    assert fs.batch_compare_faces([np.zeros(4), np.ones(4)]) == meta["empty_batch"]
+    assert fs.cluster_faces() == meta["empty_clusters"]
+    assert fs.health_check() == meta["health_empty"]
+
+
+def test_gallery_name_table_survives_delete_and_update():
+    rng = np.random.default_rng(1)
+    fs = FaceService(engine=FakeEngine())
+    E = rng.standard_normal((6, 512))
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    for i in range(6):
+        fs.store_face(f"p{i}", E[i])
+    assert fs.delete_face("p1")["success"] and not fs.delete_face("p1")["success"]
+    assert fs.get_all_targets() == ["p0", "p2", "p3", "p4", "p5"]           # dict order kept (device row of p5 moved)
+    for i in (0, 2, 3, 4, 5):
+        top = fs.find_k_nearest(E[i], 1)[0]
+        assert top["target"] == f"p{i}" and top["distance"] < 1e-6
+    assert np.allclose(fs.ENCODINGS["p5"], E[5]) and "p1" not in fs.ENCODINGS and len(fs.ENCODINGS) == 5
+    fs.store_face("p2", E[1])                                                # overwrite
+    assert fs.find_k_nearest(E[1], 1)[0]["target"] == "p2"
+
+
+def test_quality_matches_reference_geometry_and_formulas(golden):
+    meta, _ = golden
+    fs = FaceService(engine=FakeEngine())
+    img = np.zeros((480, 640, 3), np.uint8)
+    for q in meta["quality"]:
+        got = fs.assess_face_quality(img, tuple(q["loc"]))
+        for k in ("size_score", "position_score", "aspect_score"):
+            assert got[k] == q["result"][k]
+    # blur / lighting on a known pattern: checkerboard of 0/255 -> Laplacian variance and std are closed-form
+    yy, xx = np.mgrid[0:64, 0:64]
+    cb = (((yy + xx) % 2) * 255).astype(np.uint8)
+    g = fs.assess_face_quality(np.stack([cb] * 3, -1), (0, 64, 64, 0))
+    assert g["blur_score"] == 100.0 and abs(g["lighting_score"] - (100.0 - 0.5 / 128 * 100 + 100.0) / 2) < 0.5
+    flat = fs.assess_face_quality(np.full((64, 64, 3), 128, np.uint8), (0, 64, 64, 0))
+    assert flat["blur_score"] == 0.0 and "Image is blurry - use better focus or steady camera" in flat["issues"]
+    assert fs.get_quality_statistics()["total_assessments"] == len(meta["quality"]) + 2
+
+
+def test_encode_and_stream_formatting_from_device_results():
+    eng = FakeEngine()
+    B, K = 1, 4
+    emb = np.zeros((B, K, 512), np.float32)
+    emb[0, 0, 0] = emb[0, 1, 1] = 1.0
+    eng.canned = dict(boxes=np.array([[[10.7, 20.2, 110.9, 140.1], [-5.0, 3.0, 700.0, 500.0], [0] * 4, [0] * 4]], np.float32),
+                      kps=np.zeros((B, K, 5, 2), np.float32), scores=np.array([[0.9, 0.8, 0, 0]], np.float32),
+                      counts=np.array([2], np.int32), emb=emb,
+                      match_idx=np.array([[1, 0, -1, -1]], np.int32), match_cos=np.array([[0.98, 0.5, -1, -1]], np.float32))
+    fs = FaceService(engine=eng)
+    r = fs.encode_face(np.zeros((480, 640, 3), np.uint8), return_locations=True)
+    assert r["success"] and r["face_count"] == 2 and r["message"] == "Successfully encoded 2 face(s)"
+    assert r["locations"] == [(20, 110, 140, 10), (3, 640, 480, 0)]           # (top,right,bottom,left), clipped
+    assert r["encodings"][0].dtype == np.float64 and r["encodings"][0].shape == (512,)
+    assert box_to_location([1.9, 2.9, 3.9, 4.9], 100, 100) == (2, 3, 4, 1)
+    fs.store_face("alice", emb[0, 0])
+    fs.store_face("bob", emb[0, 1])
+    faces = fs.process_frames(np.zeros((1, 480, 640, 3), np.uint8), max_faces=K)[0]
+    assert [f["target"] for f in faces] == ["bob", "alice"]
+    assert faces[0]["match"] and faces[0]["confidence"] == "high" and abs(faces[0]["distance"] - 0.2) < 1e-6
+    assert not faces[1]["match"] and faces[1]["confidence"] == "low"
+    eng.canned["counts"] = np.array([0], np.int32)
+    r = fs.encode_face(np.zeros((480, 640, 3), np.uint8))
+    assert r == {"success": False, "face_count": 0, "encodings": [], "message": "No faces detected in image",
+                 "processing_time": r["processing_time"]}
+    assert fs.encode_face(12345)["message"] == "Invalid input type"
+    m = fs.get_performance_metrics()
+    assert m["total_encodings"] == 4 and m["failed_encodings"] == 1
+
+
+# ------------------------------------------------------------------ layer tables / folding / blob
+def test_layer_tables_match_published_work():
+    emb = netspec.iresnet_layers()
+    macs, _ = netspec.layer_macs(emb, 112, 112, "emb.in")
+    assert macs == 12_089_606_144                      # 12,089.6 MMAC = 24.18 GFLOP per face
+    det = netspec.detector_layers()
+    dm, per = netspec.layer_macs(det, 1088, 1920, "det.in")
+    assert dm == 72_956_405_760
+    assert netspec.num_anchors(1088, 1920) == 85680 and netspec.num_anchors(640, 640) == 16800
+    r50, _ = netspec.layer_macs(netspec.iresnet_layers((3, 4, 14, 3)), 112, 112, "emb.in")
+    assert abs(r50 * 2 / 1e9 - 12.62) < 0.05
+
+
+def _apply_folded(x_nchw, w16, bias, slope, l):
+    """fp32 evaluation of a folded layer exactly as the kernel defines it."""
+    w = torch.from_numpy(w16.astype(np.float32)).permute(0, 3, 1, 2)
+    y = F.conv2d(x_nchw, w, None, stride=l.stride, padding=l.k // 2)
+    _, _, Ho, Wo = y.shape
+    if l.flags & netspec.FLAG_BORDER_BIAS:
+        cy = np.where(np.arange(Ho) == 0, 0, np.where(np.arange(Ho) == Ho - 1, 2, 1))
+        cx = np.where(np.arange(Wo) == 0, 0, np.where(np.arange(Wo) == Wo - 1, 2, 1))
+        b = torch.from_numpy(bias[cy[:, None] * 3 + cx[None, :]]).permute(2, 0, 1)[None]
+    else:
+        b = torch.from_numpy(bias)[None, :, None, None]
+    y = y + b
+    return y
+
+
+def test_bn_folding_including_border_bias_equals_oracle_block():
+    raw = weights.make_synthetic_raw(3, (1, 1, 1, 1), (1, 1, 1, 1), want_det=False)
+    layers = {l.name: l for l in netspec.iresnet_layers((1, 1, 1, 1))}
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((2, 64, 9, 11)).astype(np.float32))
+    p = "emb.layer2.0"
+    # oracle: bn1 -> conv1 -> bn2 -> prelu
+    t = onet._bn(raw, f"{p}.bn1", x)
+    t = onet._conv(raw, f"{p}.conv1", t, 1)
+    t = F.prelu(onet._bn(raw, f"{p}.bn2", t), onet._t(raw, f"{p}.prelu.weight"))
+    l = layers[f"{p}.conv1"]
+    w16, bias, slope = weights.fold_layer(raw, l)
+    assert bias.shape == (9, 128)
+    y = _apply_folded(x, w16, bias, slope, l)
+    y = torch.where(y > 0, y, y * torch.from_numpy(slope)[None, :, None, None])
+    assert float((y - t).abs().max()) < 5e-3 * float(t.abs().max())       # only the fp16 weight rounding differs
+    # without the border classes the frame of the map would be wrong: prove the classes matter
+    y_mid = _apply_folded(x, w16, np.broadcast_to(bias[4], bias.shape).copy(), slope, l)
+    assert float((y_mid - _apply_folded(x, w16, bias, slope, l)).abs().max()) > 1e-3
+
+
+def test_fc_folding_permutes_to_nhwc():
+    raw = weights.make_synthetic_raw(5, (1, 1, 1, 1), (1, 1, 1, 1), want_det=False)
+    l = [q for q in netspec.iresnet_layers((1, 1, 1, 1)) if q.name == "emb.fc"][0]
+    w16, bias, _ = weights.fold_layer(raw, l)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 512, 7, 7)).astype(np.float32)
+    xt = torch.from_numpy(x)
+    ref = onet._bn(raw, "emb.bn2", xt).flatten(1)
+    ref = F.linear(ref, onet._t(raw, "emb.fc.weight"), onet._t(raw, "emb.fc.bias"))
+    ref = F.batch_norm(ref, onet._t(raw, "emb.features.running_mean"), onet._t(raw, "emb.features.running_var"),
+                       onet._t(raw, "emb.features.weight"), onet._t(raw, "emb.features.bias"), False, 0.0, 1e-5).numpy()
+    nhwc = np.transpose(x, (0, 2, 3, 1)).reshape(3, -1)
+    got = nhwc @ w16.reshape(512, -1).astype(np.float32).T + bias[None]
+    assert np.abs(got - ref).max() < 5e-3 * np.abs(ref).max()
+
+
+def test_blob_layout_and_buffer_liveness():
+    raw = weights.make_synthetic_raw(7, (1, 1, 1, 1), (1, 1, 1, 1))
+    blob = weights.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1))
+    hdr = struct.unpack(weights.HEADER_FMT, blob[:weights.HEADER_BYTES])
+    assert hdr[0] == b"FRPBLOB1" and hdr[1] == 1 and hdr[2] == 128
+    n_det, n_det_bufs = hdr[3], hdr[4]
+    det_off, emb_off, data_off, data_bytes = hdr[19], hdr[20], hdr[21], hdr[22]
+    assert data_off % 256 == 0 and data_off + data_bytes == len(blob)
+    ops = [struct.unpack(weights.OP_FMT, blob[det_off + i * 64: det_off + (i + 1) * 64]) for i in range(n_det)]
+    layers = netspec.detector_layers((1, 1, 1, 1))
+    assert len(ops) == len(layers)
+    # replay liveness: a physical buffer may only be overwritten once its previous tensor is dead
+    holder, last_use = {}, {}
+    for i, l in enumerate(layers):
+        last_use[l.src] = i
+        if l.res:
+            last_use[l.res] = i
+    for i, (l, op) in enumerate(zip(layers, ops)):
+        in_buf, out_buf, res_buf = op[0], op[1], op[2]
+        assert holder.get(in_buf, l.src) == l.src and in_buf != out_buf and res_buf != out_buf
+        if l.res:
+            assert holder[res_buf] == l.res
+        prev = holder.get(out_buf)
+        assert prev is None or last_use.get(prev, -1) < i, f"{l.name} overwrites live {prev}"
+        holder[out_buf] = l.dst
+        holder.setdefault(in_buf, l.src)
+        assert op[10] % 16 == 0 and op[11] % 16 == 0 and 0 <= out_buf < n_det_bufs
