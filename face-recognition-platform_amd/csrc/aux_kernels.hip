@@ -223,4 +223,44 @@ hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ benchmark helper
+// uniform [-scale, scale) fp16 fill from a counter hash (tuning runs must use random data:
+// zero operands raise the clock and flatter the kernel)
+__global__ __launch_bounds__(256) void fill_random_f16_kernel(_Float16* __restrict__ p, long n, unsigned seed, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (_Float16)(((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+    }
+}
+
+// pure MFMA loop on register operands (no memory traffic): the practical matrix-core ceiling
+// of this device at the clock it holds under load (tuning reference only)
+typedef float floatx16_ __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_peak_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int iters) {
+    half8 a = *reinterpret_cast<const half8*>(src + (threadIdx.x & 63) * 8);
+    half8 b = *reinterpret_cast<const half8*>(src + 512 + (threadIdx.x & 63) * 8);
+    floatx16_ c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, b, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, iters);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_random_f16_kernel, dim3(4096), dim3(256), 0, stream, p, n, seed, scale);
+    return hipGetLastError();
+}
+
 }  // namespace frp

@@ -14,15 +14,22 @@
 // epilogue (bias / 9-class border bias, residual, ReLU / PReLU) stores 8-byte fp16x4
 // runs into the NHWC row of that pixel.
 //
-// Tile: TP pixels x TC couts x 64 k per step, 4 waves (one per SIMD), v_mfma_f32_32x32x16_f16.
-// Staging: 16-byte global loads -> registers -> ds_write_b128 into a double-buffered,
-// XOR-swizzled LDS image (chunk ^= (row>>1)&7: conflict-free for ds_read_b128 fragment
-// reads of 128-byte rows), loads for step k+1 issued before the MFMAs of step k.
-// Zero padding and ragged tiles are predicated in the loader (no padded copies in HBM).
-// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of
-// tiles and the cout tiles of one pixel tile run back to back on the same L2.
+// Structure (one workgroup per CU, 8 waves = 2 per SIMD, v_mfma_f32_32x32x16_f16):
+//   * tile TP pixels x TC couts x 64 k per step; each wave owns a 64x64 (or 32x64) sub-tile;
+//   * operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per
+//     wave-instruction, no staging VGPRs) into a 3-stage ring: the DMA of step k+2 is
+//     issued while step k is multiplied, waits are COUNTED (`s_waitcnt vmcnt(N)`, never 0
+//     in the steady state) and there is one raw `s_barrier` per k-step;
+//   * zero padding, ragged pixel tiles and ragged cout tiles cost nothing: the per-lane
+//     buffer offset is pushed out of range and the hardware range check writes zeros;
+//   * the LDS image is rows of 128 B with chunk ^= (row>>1)&7 (conflict-free for the
+//     ds_read_b128 fragment reads); the DMA destination is lane-linear, so the swizzle is
+//     applied to the per-lane SOURCE chunk;
+//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of
+//     tiles and the cout tiles of one pixel tile run back to back on the same L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "frp_internal.h"
 
 namespace frp {
@@ -32,227 +39,332 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#define CONV_NW 8            // waves per workgroup
+#define CONV_NS 3            // LDS ring stages
+#define CONV_OOB 0x80000000u // buffer offset beyond any tensor (< 2 GiB each): reads as zero
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// select-to-zero as per-dword AND (a uint4 ?: makes hipcc round-trip through scratch)
-__device__ __forceinline__ uint4 mask4(uint4 v, bool ok) {
-    const unsigned m = ok ? 0xffffffffu : 0u;
-    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+// one LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets to lds_base + lane*16.
+// (kept in a __device__ function: the builtin does not exist for the host pass)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, unsigned voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
+}
+
+// (device-only constructs must live in __device__ functions: written directly in the __global__
+// template body they make the HOST pass drop the kernel stub without a diagnostic)
+__device__ __forceinline__ void keep_alive(floatx16 v) { asm volatile("" ::"v"(v)); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
 }
 
 template <int TP, int TC, int WP, int WC, bool SMALL>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XB = TP * 128;          // bytes of one X stage
+    constexpr int XB = TP * 128;              // bytes of one X stage
     constexpr int WB = TC * 128;
     constexpr int STAGE = XB + WB;
-    constexpr int XR = TP / 32;           // rows per thread per stage
-    constexpr int WR = TC / 32;
-    constexpr int MP = TP / WP / 32;      // MFMA tiles per wave (pixels)
-    constexpr int MC = TC / WC / 32;      // MFMA tiles per wave (couts)
-    static_assert(WP * WC == 4, "4 waves");
+    constexpr int XI = TP / 8 / CONV_NW;      // X DMA instructions per wave per stage
+    constexpr int WI = TC / 8 / CONV_NW;      // W DMA instructions per wave per stage
+    constexpr int LPS = XI + WI;              // DMA instructions per wave per stage
+    constexpr int MP = TP / WP / 32;          // MFMA tiles per wave (pixels)
+    constexpr int MC = TC / WC / 32;          // MFMA tiles per wave (couts)
+    static_assert(WP * WC == CONV_NW && XI >= 1 && WI >= 1, "tile/wave layout");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
-    // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give them consecutive tiles
-    int wid;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, j = b >> 3;
-        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int ptile = wid / p.n_ctiles;
-    const int ctile = wid - ptile * p.n_ctiles;
-    const int m0 = ptile * TP;
-    const int c0 = ctile * TC;
+    // Persistent workgroup: a contiguous range of tiles (tile = ptile * n_ctiles + ctile, so the
+    // cout tiles of one pixel tile follow each other on the same CU and L2).
+    const int n_tiles = p.n_ptiles * p.n_ctiles;
+    const int t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+    const int t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+    if (t0 >= t1) return;
+    const int nk = p.nk;
 
-    // ---------------- loader state
-    const int lrow = t >> 3, lchunk = t & 7;
-    long xbase[XR];
-    int iy0[XR], ix0[XR];
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---------------- DMA lane state of the ISSUE cursor (it runs two stages ahead of the MFMAs
+    // and crosses into the next tile while the current one is still being multiplied).
+    // Instruction i of this wave fills LDS row group g = i*NW + wave (8 rows x 128 B); lane ->
+    // row g*8 + lane/8, chunk position lane%8, which must hold logical chunk pos ^ ((row>>1)&7).
+    // NW is even, so (row>>1)&7 is the same for every i: ((wave&1)<<2) | (lane>>4).
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // logical 16-B chunk of this lane
     const int HoWo = p.Ho * p.Wo;
+    int xoff[XI];          // byte offset of (n, iy0, ix0, c=0); may be "negative" (wraps) at the border
+    int iy0[XI], ix0[XI];
+    unsigned woff[WI];     // byte offset of (cout row, k=chunk); rows >= Cout are out of range -> zeros
+    int kh = 0, kw = 0, cb = 0;               // aligned path: uniform (tap, 64-channel block) walk
+    const int cpt = p.Cin >> 6;
+    int it = t0, iks = 0, ibuf = 0;           // issue cursor: tile, k-step, ring slot
+    auto setup_issue_tile = [&](int tile) {
+        const int ptile = tile / p.n_ctiles;
+        const int m0i = ptile * TP;
+        const int c0i = (tile - ptile * p.n_ctiles) * TC;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        if (m < p.M) {
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            iy0[i] = oy * p.stride - p.pad;
-            ix0[i] = ox * p.stride - p.pad;
-            xbase[i] = (((long)n * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin;
-        } else {
-            iy0[i] = -(1 << 24);
-            ix0[i] = -(1 << 24);
-            xbase[i] = 0;
-        }
-    }
-    long wbase[WR];
-    bool wvalid[WR];
-#pragma unroll
-    for (int i = 0; i < WR; ++i) {
-        const int co = c0 + lrow + 32 * i;
-        wvalid[i] = co < p.Cout;
-        wbase[i] = (long)co * p.Ktot;
-    }
-
-    uint4 xreg[XR], wreg[WR];
-    bool xok[XR], wok[WR];   // zero-fill masks, applied at ds_write time so the loads stay in flight
-
-    // aligned path: uniform (kh, kw, cblk) walk
-    int kh = 0, kw = 0, cb = 0;
-    const int cpt = p.Cin >> 6;   // 64-channel blocks per tap (aligned path)
-
-    auto load_stage = [&](int ks) {
-        if constexpr (!SMALL) {
-            const int off = (kh * p.W + kw) * p.Cin + (cb << 6) + (lchunk << 3);
-#pragma unroll
-            for (int i = 0; i < XR; ++i) {
-                const bool ok = (unsigned)(iy0[i] + kh) < (unsigned)p.H && (unsigned)(ix0[i] + kw) < (unsigned)p.W;
-                // unconditional load from a safe address + select: no divergent branch per load
-                xreg[i] = *reinterpret_cast<const uint4*>(p.x + (ok ? xbase[i] + off : 0L));
-                xok[i] = ok;
+        for (int i = 0; i < XI; ++i) {
+            const int m = m0i + (i * CONV_NW + wave) * 8 + lrow;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                iy0[i] = oy * p.stride - p.pad;
+                ix0[i] = ox * p.stride - p.pad;
+                xoff[i] = (((n * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin) * 2;
+            } else {
+                iy0[i] = -(1 << 24);
+                ix0[i] = -(1 << 24);
+                xoff[i] = 0;
             }
-            const int kg = (ks << 6) + (lchunk << 3);
+        }
 #pragma unroll
-            for (int i = 0; i < WR; ++i) {
-                wreg[i] = *reinterpret_cast<const uint4*>(p.w + (wvalid[i] ? wbase[i] + kg : 0L));
-                wok[i] = wvalid[i];
+        for (int i = 0; i < WI; ++i) {
+            const int co = c0i + (i * CONV_NW + wave) * 8 + lrow;
+            woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
+        }
+        kh = kw = cb = 0;
+    };
+
+    // One stage = LPS DMA pieces per wave.  `prep_stage` computes the per-lane source offsets of
+    // the stage under the issue cursor (VALU only); the pieces are fired one or two at a time
+    // BETWEEN the MFMA groups of the current step, so their issue cost hides under matrix time.
+    unsigned vo[LPS];
+    auto prep_stage = [&]() {
+        const int ks = iks;
+        if constexpr (!SMALL) {
+            const int tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bool ok = (unsigned)(iy0[i] + kh) < (unsigned)p.H && (unsigned)(ix0[i] + kw) < (unsigned)p.W;
+                vo[i] = ok ? (unsigned)(xoff[i] + tapoff) : CONV_OOB;
             }
             if (++cb == cpt) { cb = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
         } else {
-            const int kg = (ks << 6) + (lchunk << 3);
+            const int kg = (ks << 6) + lchunk * 8;
             const bool kok = kg < p.Ktot;
             const int tap = kg >> p.cin_shift;
             const int ci = kg & (p.Cin - 1);
             const int tkh = (p.KS == 3) ? tap / 3 : 0;
             const int tkw = tap - tkh * p.KS;
-            const int off = (tkh * p.W + tkw) * p.Cin + ci;
+            const int tapoff = ((tkh * p.W + tkw) * p.Cin + ci) * 2;
 #pragma unroll
-            for (int i = 0; i < XR; ++i) {
+            for (int i = 0; i < XI; ++i) {
                 const bool ok = kok && (unsigned)(iy0[i] + tkh) < (unsigned)p.H && (unsigned)(ix0[i] + tkw) < (unsigned)p.W;
-                xreg[i] = *reinterpret_cast<const uint4*>(p.x + (ok ? xbase[i] + off : 0L));
-                xok[i] = ok;
-            }
-#pragma unroll
-            for (int i = 0; i < WR; ++i) {
-                const bool ok = wvalid[i] && kok;
-                wreg[i] = *reinterpret_cast<const uint4*>(p.w + (ok ? wbase[i] + kg : 0L));
-                wok[i] = ok;
+                vo[i] = ok ? (unsigned)(xoff[i] + tapoff) : CONV_OOB;
             }
         }
+        // weights: a k chunk beyond Ktot (small-Cin tail) would read the NEXT row, so guard it
+        const bool kin = SMALL ? ((ks << 6) + lchunk * 8) < p.Ktot : true;
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            vo[XI + i] = (kin && woff[i] != CONV_OOB) ? woff[i] + (unsigned)(ks << 7) : CONV_OOB;
     };
-    auto store_stage = [&](int buf) {
-        unsigned char* xs = smem + buf * STAGE;
-        unsigned char* ws = xs + XB;
-#pragma unroll
-        for (int i = 0; i < XR; ++i)
-            *reinterpret_cast<uint4*>(xs + lds_off(lrow + 32 * i, lchunk)) = mask4(xreg[i], xok[i]);
-#pragma unroll
-        for (int i = 0; i < WR; ++i)
-            *reinterpret_cast<uint4*>(ws + lds_off(lrow + 32 * i, lchunk)) = mask4(wreg[i], wok[i]);
+    // after all pieces of the prepared stage are fired: advance the cursor
+    auto advance_issue = [&]() {
+        ibuf = ibuf == 2 ? 0 : ibuf + 1;
+        if (++iks == nk) {
+            iks = 0;
+            if (++it < t1) setup_issue_tile(it);
+        }
     };
-
-    floatx16 acc[MP][MC];
-#pragma unroll
-    for (int i = 0; i < MP; ++i)
-#pragma unroll
-        for (int j = 0; j < MC; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // piece j of a stage: j < XI -> pixel rows, else weight rows (j is a literal at every use)
+#define DMA_PIECE(bufv, j)                                                                              \
+    do {                                                                                                \
+        if constexpr ((j) < LPS) {                                                                      \
+            unsigned char* base_ = smem + (bufv) * STAGE;                                               \
+            if constexpr ((j) < XI)                                                                     \
+                dma16(xrsrc, base_ + ((j) * CONV_NW + wave) * 1024, vo[(j)]);                           \
+            else                                                                                        \
+                dma16(wrsrc, base_ + XB + (((j) - XI) * CONV_NW + wave) * 1024, vo[(j) < LPS ? (j) : 0]); \
+        }                                                                                               \
+    } while (0)
+    // pieces [lo, hi) with lo, hi compile-time constants and hi - lo <= 6
+#define DMA_RANGE(bufv, lo, hi)                                 \
+    do {                                                        \
+        if constexpr ((lo) + 0 < (hi)) DMA_PIECE(bufv, (lo) + 0); \
+        if constexpr ((lo) + 1 < (hi)) DMA_PIECE(bufv, (lo) + 1); \
+        if constexpr ((lo) + 2 < (hi)) DMA_PIECE(bufv, (lo) + 2); \
+        if constexpr ((lo) + 3 < (hi)) DMA_PIECE(bufv, (lo) + 3); \
+        if constexpr ((lo) + 4 < (hi)) DMA_PIECE(bufv, (lo) + 4); \
+        if constexpr ((lo) + 5 < (hi)) DMA_PIECE(bufv, (lo) + 5); \
+    } while (0)
 
     const int wave_p = wave / WC, wave_c = wave - wave_p * WC;
     const int prow0 = wave_p * (TP / WP), crow0 = wave_c * (TC / WC);
     const int fr = lane & 31, fh = lane >> 5;
 
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-
-    const int nk = p.nk;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) load_stage(ks + 1);
-        const unsigned char* xs = smem + cur * STAGE;
-        const unsigned char* ws = xs + XB;
+    // fragment registers are double-buffered: the ds_reads of sub-step kk+1 are in flight
+    // while the MFMAs of sub-step kk run
+    floatx16 acc[MP][MC];
+    half8 bf[2][MP], af[2][MC];
+    auto read_frags = [&](const unsigned char* xs, const unsigned char* ws, int kk, int S) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            half8 bf[MP], af[MC];
+        for (int i = 0; i < MP; ++i)
+            bf[S][i] = *reinterpret_cast<const half8*>(xs + lds_off(prow0 + i * 32 + fr, 2 * kk + fh));
 #pragma unroll
-            for (int i = 0; i < MP; ++i)
-                bf[i] = *reinterpret_cast<const half8*>(xs + lds_off(prow0 + i * 32 + fr, 2 * kk + fh));
+        for (int j = 0; j < MC; ++j)
+            af[S][j] = *reinterpret_cast<const half8*>(ws + lds_off(crow0 + j * 32 + fr, 2 * kk + fh));
+    };
+    auto mfma_group = [&](int S) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
 #pragma unroll
             for (int j = 0; j < MC; ++j)
-                af[j] = *reinterpret_cast<const half8*>(ws + lds_off(crow0 + j * 32 + fr, 2 * kk + fh));
-#pragma unroll
-            for (int i = 0; i < MP; ++i)
-#pragma unroll
-                for (int j = 0; j < MC; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], bf[i], acc[i][j], 0, 0, 0);
-        }
-        if (ks + 1 < nk) store_stage(cur ^ 1);
-        __syncthreads();
-    }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[S][j], bf[S][i], acc[i][j], 0, 0, 0);
+    };
+    // DMA pieces fired after MFMA group kk: an even split of LPS over the 4 sub-steps
+    constexpr int Q1 = (LPS + 3) / 4, Q2 = (LPS + 1) / 2, Q3 = (3 * LPS + 3) / 4;
 
-    // ---------------- epilogue
+    // ---------------- the stage stream: 3-slot ring, one barrier per k-step, continuous over tiles
+    const int total = (t1 - t0) * nk;          // stages this workgroup consumes
+    setup_issue_tile(t0);
+    prep_stage(); DMA_RANGE(0, 0, LPS); advance_issue();
+    int issued = 1;
+    if (total > 1) { prep_stage(); DMA_RANGE(1, 0, LPS); advance_issue(); issued = 2; }
+    int buf = 0, consumed = 0;
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
     const bool out32 = p.flags & FRP_FLAG_OUT_F32;
     const bool up2 = p.flags & FRP_FLAG_RES_UP2;
+    const bool has_res = p.res != nullptr;
+    const bool prelu = p.act == FRP_ACT_PRELU;
+    const bool relu = p.act == FRP_ACT_RELU;
+
+    for (int ct = t0; ct < t1; ++ct) {
 #pragma unroll
-    for (int i = 0; i < MP; ++i) {
-        const int m = m0 + prow0 + i * 32 + fr;
-        if (m >= p.M) continue;
-        int cls = 0;
-        long ridx = (long)m * p.Cout;
-        if (border || up2) {
-            const int n = m / HoWo;
-            const int rem = m - n * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            if (border) cls = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-            if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int ks = 0; ks < nk; ++ks) {
+            // The stage to consume has landed for THIS wave once only the newest stage (LPS
+            // pieces) may still be pending.  Right after an epilogue its stores are pending too
+            // (vmcnt counts them, in issue order, behind the DMAs), so drain everything there.
+            if (issued - consumed >= 2 && !(ks == 0 && ct != t0)) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            // every wave's DMA of this stage is in LDS, and every wave is done reading the previous
+            // stage, whose ring slot the next issue goes into
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* xs = smem + buf * STAGE;
+            const unsigned char* ws = xs + XB;
+            const bool more = issued < total && !(p.dbg & 1);
+            const bool mm = !(p.dbg & 2);
+            const int nbuf = ibuf;
+            if (mm) read_frags(xs, ws, 0, 0);
+            if (more) prep_stage();
+            if (mm) { read_frags(xs, ws, 1, 1); mfma_group(0); }
+            if (more) DMA_RANGE(nbuf, 0, Q1);
+            if (mm) { read_frags(xs, ws, 2, 0); mfma_group(1); }
+            if (more) DMA_RANGE(nbuf, Q1, Q2);
+            if (mm) { read_frags(xs, ws, 3, 1); mfma_group(0); }
+            if (more) DMA_RANGE(nbuf, Q2, Q3);
+            if (mm) mfma_group(1);
+            if (more) { DMA_RANGE(nbuf, Q3, LPS); advance_issue(); ++issued; }
+            ++consumed;
+            buf = buf == 2 ? 0 : buf + 1;
         }
-        const float* bias = p.bias + (long)cls * p.Cout;
-        const long obase = (long)m * p.Cout;
+
+        if (p.dbg & 4) {   // tuning ablation: no epilogue (keep the accumulators alive)
 #pragma unroll
-        for (int j = 0; j < MC; ++j) {
+            for (int i = 0; i < MP; ++i)
+#pragma unroll
+                for (int j = 0; j < MC; ++j) keep_alive(acc[i][j]);
+            continue;
+        }
+        // ---------------- epilogue of tile ct (accumulator layout: lane = one pixel, 4 consecutive
+        // couts per register group): bias / border-class bias, residual, activation in fp32, fp16
+        // (or fp32) stores straight from registers while the next tile's first stages are already
+        // in flight.  All bias / slope / residual loads of a pixel row are issued back to back
+        // from clamped (always valid) addresses before any is consumed; stores are predicated.
+        const int ptile = ct / p.n_ctiles;
+        const int m0 = ptile * TP;
+        const int c0 = (ct - ptile * p.n_ctiles) * TC;
+        int co_[MC][4];
+        bool cok[MC][4];
+        floatx4 s4[MC][4];
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                if (co >= p.Cout) continue;
-                floatx4 v;
-                const floatx4 b4 = *reinterpret_cast<const floatx4*>(bias + co);
+                cok[j][g] = co < p.Cout;
+                co_[j][g] = cok[j][g] ? co : 0;
+                if (prelu) s4[j][g] = *reinterpret_cast<const floatx4*>(p.slope + co_[j][g]);
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[e];
-                if (p.res) {
-                    const half4 r4 = *reinterpret_cast<const half4*>(p.res + ridx + co);
+        for (int i = 0; i < MP; ++i) {
+            const int mraw = m0 + prow0 + i * 32 + fr;
+            const bool mok = mraw < p.M;
+            const int m = mok ? mraw : 0;
+            int cls = 0;
+            long ridx = (long)m * p.Cout;
+            if (border || up2) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                if (border) cls = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+                if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+            }
+            const float* bias = p.bias + (long)cls * p.Cout;
+            const long obase = (long)m * p.Cout;
+            floatx4 b4[MC][4];
+            half4 r4[MC][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                }
-                if (p.act == FRP_ACT_RELU) {
+            for (int j = 0; j < MC; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                } else if (p.act == FRP_ACT_PRELU) {
-                    const floatx4 s4 = *reinterpret_cast<const floatx4*>(p.slope + co);
+                for (int g = 0; g < 4; ++g) b4[j][g] = *reinterpret_cast<const floatx4*>(bias + co_[j][g]);
+            if (has_res) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[e];
-                }
-                if (out32) {
-                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase + co) = v;
-                } else {
-                    half4 h;
+                for (int j = 0; j < MC; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                    *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + obase + co) = h;
+                    for (int g = 0; g < 4; ++g) r4[j][g] = *reinterpret_cast<const half4*>(p.res + ridx + co_[j][g]);
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[j][g][e];
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[j][g][e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (prelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[j][g][e];
+                    }
+                    if (mok && cok[j][g]) {
+                        if (out32) {
+                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase + co_[j][g]) = v;
+                        } else {
+                            half4 h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + obase + co_[j][g]) = h;
+                        }
+                    }
                 }
             }
         }
     }
+#undef DMA_RANGE
+#undef DMA_PIECE
 }
 
 template <int TP, int TC, int WP, int WC, bool SMALL>
@@ -260,7 +372,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = 2 * (TP + TC) * 128;
+    const int lds = CONV_NS * (TP + TC) * 128;
     static bool attr_set[64] = {};
     auto kern = conv_mfma_kernel<TP, TC, WP, WC, SMALL>;
     int dev = 0;
@@ -271,9 +383,18 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    const long nwg = (long)p.n_ptiles * p.n_ctiles;
-    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    static int n_cu[64] = {};
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // persistent: one workgroup per CU (the 144 KiB ring allows exactly one), each walks a
+    // contiguous range of tiles
+    const unsigned grid = (unsigned)(ntiles < n_cu[dev] ? ntiles : n_cu[dev]);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -282,7 +403,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
 hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     ConvParams p = in;
     if (!(p.KS == 1 || p.KS == 3) || !(p.stride == 1 || p.stride == 2)) return hipErrorInvalidValue;
-    if (p.Cin < 8 || (p.Cin & 7) || (p.Cout & 3) || p.N <= 0 || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
+    if (p.Cin < 8 || (p.Cin & 7) || (p.Cout & 7) || p.N <= 0 || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
     p.pad = p.KS / 2;
     p.Ho = (p.H + 2 * p.pad - p.KS) / p.stride + 1;
     p.Wo = (p.W + 2 * p.pad - p.KS) / p.stride + 1;
@@ -291,6 +412,11 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     p.M = (int)M;
     p.Ktot = p.KS * p.KS * p.Cin;
     p.nk = (p.Ktot + 63) / 64;
+    // buffer descriptors carry 32-bit sizes and the kernel does signed 32-bit offset math
+    const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * p.Ktot * 2;
+    if (xb >= 0x7fffffffL || wb >= 0x7fffffffL) return hipErrorInvalidValue;
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
     const bool small = (p.Cin & 63) != 0;
     p.cin_shift = 0;
     if (small) {
@@ -302,12 +428,10 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if ((p.flags & FRP_FLAG_RES_UP2) && (!p.res || p.Hr * 2 != p.Ho || p.Wr * 2 != p.Wo)) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.bias || !p.out) return hipErrorInvalidValue;
     if (p.act == FRP_ACT_PRELU && !p.slope) return hipErrorInvalidValue;
-    if (p.Cout >= 128) {
-        return small ? launch_cfg<128, 128, 2, 2, true>(p, stream) : launch_cfg<128, 128, 2, 2, false>(p, stream);
-    } else if (p.Cout > 32) {
-        return small ? launch_cfg<256, 64, 4, 1, true>(p, stream) : launch_cfg<256, 64, 4, 1, false>(p, stream);
+    if (p.Cout > 64) {
+        return small ? launch_cfg<256, 128, 4, 2, true>(p, stream) : launch_cfg<256, 128, 4, 2, false>(p, stream);
     } else {
-        return small ? launch_cfg<256, 32, 4, 1, true>(p, stream) : launch_cfg<256, 32, 4, 1, false>(p, stream);
+        return small ? launch_cfg<256, 64, 8, 1, true>(p, stream) : launch_cfg<256, 64, 8, 1, false>(p, stream);
     }
 }
 

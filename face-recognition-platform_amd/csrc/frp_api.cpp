@@ -907,6 +907,79 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     return FRP_OK;
 }
 
+int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!ms_avg || iters <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(h, FRP_ERR_INVALID, "bad bench arguments");
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const size_t xn = (size_t)N * H * W * Cin, wn = (size_t)Cout * ksize * ksize * Cin, on = (size_t)N * Ho * Wo * Cout;
+    DevBuf dx, dw, db, ds, dr, dout;
+    int rc = ensure(h, dx, xn * 2);
+    if (rc == FRP_OK) rc = ensure(h, dw, wn * 2);
+    if (rc == FRP_OK) rc = ensure(h, db, (size_t)Cout * 4 * 9);
+    if (rc == FRP_OK) rc = ensure(h, ds, (size_t)Cout * 4);
+    if (rc == FRP_OK) rc = ensure(h, dr, on * 2);
+    if (rc == FRP_OK) rc = ensure(h, dout, on * 4);
+    hipError_t e = hipSuccess;
+    float ms = 0.f;
+    if (rc == FRP_OK) {
+        e = launch_fill_random_f16((_Float16*)dx.p, (long)xn, 1u, 1.0f, h->stream);
+        if (e == hipSuccess) e = launch_fill_random_f16((_Float16*)dw.p, (long)wn, 2u, 1.0f / sqrtf((float)(ksize * ksize * Cin)), h->stream);
+        if (e == hipSuccess) e = launch_fill_random_f16((_Float16*)dr.p, (long)on, 3u, 1.0f, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(db.p, 0, (size_t)Cout * 36, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ds.p, 0, (size_t)Cout * 4, h->stream);
+        ConvParams p{};
+        p.x = (const _Float16*)dx.p; p.w = (const _Float16*)dw.p; p.bias = (const float*)db.p; p.slope = (const float*)ds.p;
+        p.res = with_res ? (const _Float16*)dr.p : nullptr; p.out = dout.p;
+        p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
+        p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32);
+        p.dbg = (flags >> 8) & 15;
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, h->stream);   // warm-up
+        if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_conv(p, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev[1], h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout};
+    for (DevBuf* b : all) release(*b);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("conv_bench: ") + hipGetErrorString(e));
+    *ms_avg = ms / iters;
+    return FRP_OK;
+}
+
+int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!tflops || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return fail(h, FRP_ERR_INVALID, "bad arguments");
+    const int blocks = 256 * waves_per_simd;   // 256 CUs x (4 waves per block = one per SIMD)
+    DevBuf src, dst;
+    int rc = ensure(h, src, 4096);
+    if (rc == FRP_OK) rc = ensure(h, dst, (size_t)blocks * 256 * 4);
+    hipError_t e = hipSuccess;
+    float ms = 0.f;
+    if (rc == FRP_OK) {
+        e = launch_fill_random_f16((_Float16*)src.p, 2048, 7u, 1.0f, h->stream);
+        if (e == hipSuccess) e = launch_mfma_peak((const _Float16*)src.p, (float*)dst.p, blocks, iters, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
+        if (e == hipSuccess) e = launch_mfma_peak((const _Float16*)src.p, (float*)dst.p, blocks, iters, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev[1], h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    release(src);
+    release(dst);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("mfma_peak: ") + hipGetErrorString(e));
+    *tflops = (float)((double)blocks * 4 * iters * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+    return FRP_OK;
+}
+
 int frp_get_counters(frp_handle* h, frp_counters* out) {
     if (!h || !out) return FRP_ERR_INVALID;
     Guard g(h);

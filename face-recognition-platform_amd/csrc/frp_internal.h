@@ -27,8 +27,10 @@ struct ConvParams {
     int N, H, W, Cin, Cout, KS, stride;
     int act, flags;
     int Hr, Wr;             // residual spatial dims (RES_UP2)
+    int dbg;                // tuning ablations (conv_bench only): 1 = no DMA in the loop, 2 = no MFMA
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
+    unsigned x_bytes, w_bytes;   // buffer-descriptor sizes (each < 2 GiB)
 };
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
@@ -75,6 +77,9 @@ hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int
 hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream);
 // gallery upload: fp32 rows -> unit fp16 rows
 hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
+
+hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream);
+hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream);
 
 // K6: cosine match, top-1 (and optional full score matrix)
 struct MatchParams {

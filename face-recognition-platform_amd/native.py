@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "frp_gallery_size", "frp_gallery_get",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_detect", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
-    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_get_counters", "frp_reset_counters",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_get_counters", "frp_reset_counters",
 ]
 
 
@@ -92,6 +92,8 @@ def load_library() -> C.CDLL:
     lib.frp_match.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.frp_match_scores.argtypes = [vp, vp, i32, vp]
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float)]
+    lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
     lib.frp_reset_counters.argtypes = [vp]
     _lib = lib
@@ -299,6 +301,16 @@ class Engine:
         self._chk(self._lib.frp_conv2d_nhwc(self._h, _ptr(x), N, H, W, Cin, _ptr(w), Cout, k, stride, _ptr(bias), _ptr(slope),
                                             _ptr(res), rh, rw, act, flags, _ptr(out)))
         return out
+
+    def conv_bench(self, N, H, W, Cin, Cout, k=3, stride=1, act=0, flags=0, with_res=False, iters=20) -> float:
+        ms = C.c_float()
+        self._chk(self._lib.frp_conv_bench(self._h, N, H, W, Cin, Cout, k, stride, act, flags, int(with_res), iters, C.byref(ms)))
+        return float(ms.value)
+
+    def mfma_peak(self, waves_per_simd=1, iters=20000) -> float:
+        t = C.c_float()
+        self._chk(self._lib.frp_mfma_peak(self._h, waves_per_simd, iters, C.byref(t)))
+        return float(t.value)
 
     def counters(self) -> dict:
         c = FrpCounters()

@@ -168,6 +168,14 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
                     const float* bias, const float* slope, const void* res, int32_t res_h, int32_t res_w,
                     int32_t act, int32_t flags, void* out);
 
+/* tuning hook: average milliseconds of `iters` back-to-back launches of one conv shape on
+ * random device-resident operands (HIP events on the handle's stream) */
+int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg);
+
+/* tuning hook: sustained v_mfma_f32_32x32x16_f16 rate of this device on register operands */
+int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops);
+
 /* ---- observability ---------------------------------------------------------------
  * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */
 int frp_get_counters(frp_handle* h, frp_counters* out);

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the MFMA conv kernel on the layer shapes of the headline workload
+(32 x 1080p frames, 320 faces).  Usage on the GPU box: python tools/conv_bench.py [iters]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frp_amd_loader  # noqa: E402,F401
+from frp_amd import native  # noqa: E402
+
+SHAPES = [
+    # name, N, H, W, Cin, Cout, k, stride, act, flags, res, launches per step
+    ("emb.stage3 256->256 14x14", 320, 14, 14, 256, 256, 3, 1, 2, 1, False, 30),
+    ("emb.stage3 conv2 +res",     320, 14, 14, 256, 256, 3, 1, 0, 0, True, 29),
+    ("emb.stage2 128->128 28x28", 320, 28, 28, 128, 128, 3, 1, 2, 1, False, 25),
+    ("emb.stage1 64->64 56x56",   320, 56, 56, 64, 64, 3, 1, 2, 1, False, 5),
+    ("emb.stage4 512->512 7x7",   320, 7, 7, 512, 512, 3, 1, 2, 1, False, 5),
+    ("emb.l1.0 conv1 112x112",    320, 112, 112, 64, 64, 3, 1, 2, 1, False, 1),
+    ("emb.stem 8->64 112x112",    320, 112, 112, 8, 64, 3, 1, 2, 0, False, 1),
+    ("emb.fc 25088->512",         320, 1, 1, 25088, 512, 1, 1, 0, 2, False, 1),
+    ("det.layer1 64->64 272x480", 32, 272, 480, 64, 64, 3, 1, 1, 0, False, 2),
+    ("det 128->128 136x240",      32, 136, 240, 128, 128, 3, 1, 1, 0, False, 9),
+    ("det 256->256 68x120",       32, 68, 120, 256, 256, 3, 1, 1, 0, False, 4),
+    ("det.stem1 8->32 s2 1088x1920", 32, 1088, 1920, 8, 32, 3, 2, 1, 0, False, 1),
+    ("det.stem2 32->64 s2 544x960", 32, 544, 960, 32, 64, 3, 2, 1, 0, False, 1),
+    ("det.head out 128->32",      32, 136, 240, 128, 32, 3, 1, 0, 0, False, 1),
+]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 1: no DMA in the k-loop, 2: no MFMA/LDS reads
+    eng = native.Engine(0)
+    tot = 0.0
+    for (name, N, H, W, Cin, Cout, k, s, act, flags, res, cnt) in SHAPES:
+        ms = eng.conv_bench(N, H, W, Cin, Cout, k, s, act, flags | (dbg << 8), res, iters)
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        cin_r = 3 if Cin == 8 else Cin
+        fl = 2.0 * N * Ho * Wo * k * k * cin_r * Cout
+        print(f"{name:34s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s   x{cnt:2d} = {ms*cnt:7.3f} ms")
+        tot += ms * cnt
+    print(f"weighted total {tot:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
