@@ -14,12 +14,14 @@
 // epilogue (bias / 9-class border bias, residual, ReLU / PReLU) stores 8-byte fp16x4
 // runs into the NHWC row of that pixel.
 //
-// Structure (one workgroup per CU, 8 waves = 2 per SIMD, v_mfma_f32_32x32x16_f16):
-//   * tile TP pixels x TC couts x 64 k per step; each wave owns a 64x64 (or 32x64) sub-tile;
+// Structure (persistent: one workgroup per CU walks a contiguous range of output tiles;
+// 8 waves = 2 per SIMD, v_mfma_f32_32x32x16_f16):
+//   * tile TP pixels x TC couts x 64 k per step; each wave owns a 128x64, 64x64 or 32x64 sub-tile;
 //   * operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per
-//     wave-instruction, no staging VGPRs) into a 3-stage ring: the DMA of step k+2 is
-//     issued while step k is multiplied, waits are COUNTED (`s_waitcnt vmcnt(N)`, never 0
-//     in the steady state) and there is one raw `s_barrier` per k-step;
+//     wave-instruction, no staging VGPRs) into a 2- or 3-slot ring that runs continuously
+//     ACROSS tiles (the first stages of the next tile load during the tail and the epilogue
+//     of the current one); the pieces of a stage are fired between the MFMA groups of the
+//     running step, waits are counted (`s_waitcnt vmcnt(N)`), one raw `s_barrier` per k-step;
 //   * zero padding, ragged pixel tiles and ragged cout tiles cost nothing: the per-lane
 //     buffer offset is pushed out of range and the hardware range check writes zeros;
 //   * the LDS image is rows of 128 B with chunk ^= (row>>1)&7 (conflict-free for the
@@ -39,7 +41,6 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-#define CONV_NW 8            // waves per workgroup
 #define CONV_NS 3            // LDS ring stages
 #define CONV_OOB 0x80000000u // buffer offset beyond any tensor (< 2 GiB each): reads as zero
 
@@ -56,27 +57,42 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 // (device-only constructs must live in __device__ functions: written directly in the __global__
 // template body they make the HOST pass drop the kernel stub without a diagnostic)
 __device__ __forceinline__ void keep_alive(floatx16 v) { asm volatile("" ::"v"(v)); }
+// keeps hipcc from hoisting the loads of every epilogue slice above the first one (which
+// would need several hundred live registers)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+static int device_cu_count(int dev) {
+    static int n_cu[64] = {};
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n_cu[dev];
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else static_assert(N == 0, "add the literal");
 }
 
-template <int TP, int TC, int WP, int WC, bool SMALL>
-__global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
+template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XB = TP * 128;              // bytes of one X stage
     constexpr int WB = TC * 128;
     constexpr int STAGE = XB + WB;
-    constexpr int XI = TP / 8 / CONV_NW;      // X DMA instructions per wave per stage
-    constexpr int WI = TC / 8 / CONV_NW;      // W DMA instructions per wave per stage
+    constexpr int XI = TP / 8 / NW;      // X DMA instructions per wave per stage
+    constexpr int WI = TC / 8 / NW;      // W DMA instructions per wave per stage
     constexpr int LPS = XI + WI;              // DMA instructions per wave per stage
     constexpr int MP = TP / WP / 32;          // MFMA tiles per wave (pixels)
     constexpr int MC = TC / WC / 32;          // MFMA tiles per wave (couts)
-    static_assert(WP * WC == CONV_NW && XI >= 1 && WI >= 1, "tile/wave layout");
+    constexpr int PRE = NS - 1;               // stages the DMA runs ahead of the MFMAs
+    static_assert(WP * WC == NW && XI >= 1 && WI >= 1 && LPS <= 12 && (NS == 2 || NS == 3), "tile/wave layout");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-    // ---------------- DMA lane state of the ISSUE cursor (it runs two stages ahead of the MFMAs
+    // ---------------- DMA lane state of the ISSUE cursor (it runs PRE stages ahead of the MFMAs
     // and crosses into the next tile while the current one is still being multiplied).
     // Instruction i of this wave fills LDS row group g = i*NW + wave (8 rows x 128 B); lane ->
     // row g*8 + lane/8, chunk position lane%8, which must hold logical chunk pos ^ ((row>>1)&7).
@@ -101,8 +117,8 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // logical 16-B chunk of this lane
     const int HoWo = p.Ho * p.Wo;
-    int xoff[XI];          // byte offset of (n, iy0, ix0, c=0); may be "negative" (wraps) at the border
-    int iy0[XI], ix0[XI];
+    int xoff[XI];          // byte offset of (n, iy0, ix0, c=0) + this lane's chunk; wraps at the border
+    unsigned tapmask[XI];  // bit kh*3+kw set <=> that tap of this pixel row lies inside the image
     unsigned woff[WI];     // byte offset of (cout row, k=chunk); rows >= Cout are out of range -> zeros
     int kh = 0, kw = 0, cb = 0;               // aligned path: uniform (tap, 64-channel block) walk
     const int cpt = p.Cin >> 6;
@@ -113,66 +129,68 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
         const int c0i = (tile - ptile * p.n_ctiles) * TC;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const int m = m0i + (i * CONV_NW + wave) * 8 + lrow;
+            const int m = m0i + (i * NW + wave) * 8 + lrow;
+            unsigned mask = 0;
+            int off = 0;
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
                 const int oy = rem / p.Wo;
                 const int ox = rem - oy * p.Wo;
-                iy0[i] = oy * p.stride - p.pad;
-                ix0[i] = ox * p.stride - p.pad;
-                xoff[i] = (((n * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin) * 2;
-            } else {
-                iy0[i] = -(1 << 24);
-                ix0[i] = -(1 << 24);
-                xoff[i] = 0;
+                const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+                off = (((n * p.H + y0) * p.W + x0) * p.Cin) * 2;
+                unsigned ym = 0, xm = 0;      // 3-bit validity of y0+{0,1,2}, x0+{0,1,2}
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    ym |= ((unsigned)(y0 + d) < (unsigned)p.H ? 1u : 0u) << d;
+                    xm |= ((unsigned)(x0 + d) < (unsigned)p.W ? 1u : 0u) << d;
+                }
+                if (p.KS == 1) { ym &= 1u; xm &= 1u; }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) mask |= ((ym >> d) & 1u) ? (xm << (3 * d)) : 0u;
             }
+            xoff[i] = off;
+            tapmask[i] = mask;
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const int co = c0i + (i * CONV_NW + wave) * 8 + lrow;
+            const int co = c0i + (i * NW + wave) * 8 + lrow;
             woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
         }
         kh = kw = cb = 0;
     };
 
     // One stage = LPS DMA pieces per wave.  `prep_stage` computes the per-lane source offsets of
-    // the stage under the issue cursor (VALU only); the pieces are fired one or two at a time
-    // BETWEEN the MFMA groups of the current step, so their issue cost hides under matrix time.
-    unsigned vo[LPS];
+    // the stage under the issue cursor (VALU only); the pieces are fired a few at a time BETWEEN
+    // the MFMA groups of the current step, so their issue cost hides under matrix time.
+    // per-stage uniform part of the source offset (computed once per stage, see `prep_stage`)
+    int st_tapoff = 0;
+    unsigned st_bit = 0, st_wadd = 0;
+    bool st_kin = true;
     auto prep_stage = [&]() {
         const int ks = iks;
         if constexpr (!SMALL) {
-            const int tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bool ok = (unsigned)(iy0[i] + kh) < (unsigned)p.H && (unsigned)(ix0[i] + kw) < (unsigned)p.W;
-                vo[i] = ok ? (unsigned)(xoff[i] + tapoff) : CONV_OOB;
-            }
+            st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
+            st_bit = 1u << (kh * 3 + kw);
             if (++cb == cpt) { cb = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
         } else {
             const int kg = (ks << 6) + lchunk * 8;
-            const bool kok = kg < p.Ktot;
             const int tap = kg >> p.cin_shift;
             const int ci = kg & (p.Cin - 1);
             const int tkh = (p.KS == 3) ? tap / 3 : 0;
             const int tkw = tap - tkh * p.KS;
-            const int tapoff = ((tkh * p.W + tkw) * p.Cin + ci) * 2;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bool ok = kok && (unsigned)(iy0[i] + tkh) < (unsigned)p.H && (unsigned)(ix0[i] + tkw) < (unsigned)p.W;
-                vo[i] = ok ? (unsigned)(xoff[i] + tapoff) : CONV_OOB;
-            }
+            st_tapoff = ((tkh * p.W + tkw) * p.Cin + ci) * 2;
+            st_bit = kg < p.Ktot ? 1u << (tkh * 3 + tkw) : 0u;
+            // weights: a k chunk beyond Ktot (small-Cin tail) would read the NEXT row, so guard it
+            st_kin = kg < p.Ktot;
         }
-        // weights: a k chunk beyond Ktot (small-Cin tail) would read the NEXT row, so guard it
-        const bool kin = SMALL ? ((ks << 6) + lchunk * 8) < p.Ktot : true;
-#pragma unroll
-        for (int i = 0; i < WI; ++i)
-            vo[XI + i] = (kin && woff[i] != CONV_OOB) ? woff[i] + (unsigned)(ks << 7) : CONV_OOB;
+        st_wadd = (unsigned)(ks << 7);
     };
+    auto x_off = [&](int i) -> unsigned { return (tapmask[i] & st_bit) ? (unsigned)(xoff[i] + st_tapoff) : CONV_OOB; };
+    auto w_off = [&](int i) -> unsigned { return (st_kin && woff[i] != CONV_OOB) ? woff[i] + st_wadd : CONV_OOB; };
     // after all pieces of the prepared stage are fired: advance the cursor
     auto advance_issue = [&]() {
-        ibuf = ibuf == 2 ? 0 : ibuf + 1;
+        ibuf = ibuf == NS - 1 ? 0 : ibuf + 1;
         if (++iks == nk) {
             iks = 0;
             if (++it < t1) setup_issue_tile(it);
@@ -184,9 +202,9 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
         if constexpr ((j) < LPS) {                                                                      \
             unsigned char* base_ = smem + (bufv) * STAGE;                                               \
             if constexpr ((j) < XI)                                                                     \
-                dma16(xrsrc, base_ + ((j) * CONV_NW + wave) * 1024, vo[(j)]);                           \
+                dma16(xrsrc, base_ + ((j) * NW + wave) * 1024, x_off((j) < XI ? (j) : 0));         \
             else                                                                                        \
-                dma16(wrsrc, base_ + XB + (((j) - XI) * CONV_NW + wave) * 1024, vo[(j) < LPS ? (j) : 0]); \
+                dma16(wrsrc, base_ + XB + (((j) - XI) * NW + wave) * 1024, w_off((j) >= XI && (j) < LPS ? (j) - XI : 0)); \
         }                                                                                               \
     } while (0)
     // pieces [lo, hi) with lo, hi compile-time constants and hi - lo <= 6
@@ -199,6 +217,11 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
         if constexpr ((lo) + 4 < (hi)) DMA_PIECE(bufv, (lo) + 4); \
         if constexpr ((lo) + 5 < (hi)) DMA_PIECE(bufv, (lo) + 5); \
     } while (0)
+#define DMA_ALL(bufv)                      \
+    do {                                   \
+        DMA_RANGE(bufv, 0, LPS < 6 ? LPS : 6); \
+        DMA_RANGE(bufv, 6, LPS);           \
+    } while (0)
 
     const int wave_p = wave / WC, wave_c = wave - wave_p * WC;
     const int prow0 = wave_p * (TP / WP), crow0 = wave_c * (TC / WC);
@@ -206,8 +229,9 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
 
     // fragment registers are double-buffered: the ds_reads of sub-step kk+1 are in flight
     // while the MFMAs of sub-step kk run
+    constexpr int FB = (MP * MC <= 4) ? 2 : 1;   // big wave tiles: single fragment set (register budget)
     floatx16 acc[MP][MC];
-    half8 bf[2][MP], af[2][MC];
+    half8 bf[FB][MP], af[FB][MC];
     auto read_frags = [&](const unsigned char* xs, const unsigned char* ws, int kk, int S) {
 #pragma unroll
         for (int i = 0; i < MP; ++i)
@@ -226,12 +250,19 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
     // DMA pieces fired after MFMA group kk: an even split of LPS over the 4 sub-steps
     constexpr int Q1 = (LPS + 3) / 4, Q2 = (LPS + 1) / 2, Q3 = (3 * LPS + 3) / 4;
 
-    // ---------------- the stage stream: 3-slot ring, one barrier per k-step, continuous over tiles
+    // ---------------- the stage stream: NS-slot ring, one barrier per k-step, continuous over tiles
     const int total = (t1 - t0) * nk;          // stages this workgroup consumes
     setup_issue_tile(t0);
-    prep_stage(); DMA_RANGE(0, 0, LPS); advance_issue();
-    int issued = 1;
-    if (total > 1) { prep_stage(); DMA_RANGE(1, 0, LPS); advance_issue(); issued = 2; }
+    int issued = 0;
+#pragma unroll
+    for (int s0 = 0; s0 < PRE; ++s0) {
+        if (issued < total) {
+            prep_stage();
+            if (s0 == 0) DMA_ALL(0); else DMA_ALL(1);
+            advance_issue();
+            ++issued;
+        }
+    }
     int buf = 0, consumed = 0;
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
     const bool out32 = p.flags & FRP_FLAG_OUT_F32;
@@ -249,39 +280,54 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         for (int ks = 0; ks < nk; ++ks) {
-            // The stage to consume has landed for THIS wave once only the newest stage (LPS
-            // pieces) may still be pending.  Right after an epilogue its stores are pending too
-            // (vmcnt counts them, in issue order, behind the DMAs), so drain everything there.
-            if (issued - consumed >= 2 && !(ks == 0 && ct != t0)) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            // The stage to consume has landed for THIS wave once only the newer stages may still be
+            // pending (NS=3: one stage = LPS pieces; NS=2: none).  Right after an epilogue its
+            // stores are pending too (vmcnt counts them, in issue order, behind the DMAs), so
+            // everything is drained there.
+            if (NS == 3 && issued - consumed >= 2 && !(ks == 0 && ct != t0)) wait_vmcnt<(NS == 3 ? LPS : 0)>(); else wait_vmcnt<0>();
             // every wave's DMA of this stage is in LDS, and every wave is done reading the previous
             // stage, whose ring slot the next issue goes into
             __builtin_amdgcn_s_barrier();
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XB;
-            const bool more = issued < total && !(p.dbg & 1);
-            const bool mm = !(p.dbg & 2);
             const int nbuf = ibuf;
-            if (mm) read_frags(xs, ws, 0, 0);
-            if (more) prep_stage();
-            if (mm) { read_frags(xs, ws, 1, 1); mfma_group(0); }
-            if (more) DMA_RANGE(nbuf, 0, Q1);
-            if (mm) { read_frags(xs, ws, 2, 0); mfma_group(1); }
-            if (more) DMA_RANGE(nbuf, Q1, Q2);
-            if (mm) { read_frags(xs, ws, 3, 1); mfma_group(0); }
-            if (more) DMA_RANGE(nbuf, Q2, Q3);
-            if (mm) mfma_group(1);
-            if (more) { DMA_RANGE(nbuf, Q3, LPS); advance_issue(); ++issued; }
+            read_frags(xs, ws, 0, 0);
+            if (issued < total) {                       // uniform; false only for the last PRE steps
+                prep_stage();
+                if constexpr (FB == 2) {
+                    read_frags(xs, ws, 1, 1); mfma_group(0);
+                    DMA_RANGE(nbuf, 0, Q1);
+                    read_frags(xs, ws, 2, 0); mfma_group(1);
+                    DMA_RANGE(nbuf, Q1, Q2);
+                    read_frags(xs, ws, 3, 1); mfma_group(0);
+                    DMA_RANGE(nbuf, Q2, Q3);
+                    mfma_group(1);
+                    DMA_RANGE(nbuf, Q3, LPS);
+                } else {
+                    mfma_group(0); DMA_RANGE(nbuf, 0, Q1);
+                    read_frags(xs, ws, 1, 0); mfma_group(0); DMA_RANGE(nbuf, Q1, Q2);
+                    read_frags(xs, ws, 2, 0); mfma_group(0); DMA_RANGE(nbuf, Q2, Q3);
+                    read_frags(xs, ws, 3, 0); mfma_group(0); DMA_RANGE(nbuf, Q3, LPS);
+                }
+                advance_issue();
+                ++issued;
+            } else {
+                if constexpr (FB == 2) {
+                    read_frags(xs, ws, 1, 1); mfma_group(0);
+                    read_frags(xs, ws, 2, 0); mfma_group(1);
+                    read_frags(xs, ws, 3, 1); mfma_group(0);
+                    mfma_group(1);
+                } else {
+                    mfma_group(0);
+                    read_frags(xs, ws, 1, 0); mfma_group(0);
+                    read_frags(xs, ws, 2, 0); mfma_group(0);
+                    read_frags(xs, ws, 3, 0); mfma_group(0);
+                }
+            }
             ++consumed;
-            buf = buf == 2 ? 0 : buf + 1;
+            buf = buf == NS - 1 ? 0 : buf + 1;
         }
 
-        if (p.dbg & 4) {   // tuning ablation: no epilogue (keep the accumulators alive)
-#pragma unroll
-            for (int i = 0; i < MP; ++i)
-#pragma unroll
-                for (int j = 0; j < MC; ++j) keep_alive(acc[i][j]);
-            continue;
-        }
         // ---------------- epilogue of tile ct (accumulator layout: lane = one pixel, 4 consecutive
         // couts per register group): bias / border-class bias, residual, activation in fp32, fp16
         // (or fp32) stores straight from registers while the next tile's first stages are already
@@ -290,18 +336,6 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
         const int ptile = ct / p.n_ctiles;
         const int m0 = ptile * TP;
         const int c0 = (ct - ptile * p.n_ctiles) * TC;
-        int co_[MC][4];
-        bool cok[MC][4];
-        floatx4 s4[MC][4];
-#pragma unroll
-        for (int j = 0; j < MC; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                cok[j][g] = co < p.Cout;
-                co_[j][g] = cok[j][g] ? co : 0;
-                if (prelu) s4[j][g] = *reinterpret_cast<const floatx4*>(p.slope + co_[j][g]);
-            }
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
             const int mraw = m0 + prow0 + i * 32 + fr;
@@ -319,62 +353,71 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_mfma_kernel(ConvParams p) {
             }
             const float* bias = p.bias + (long)cls * p.Cout;
             const long obase = (long)m * p.Cout;
-            floatx4 b4[MC][4];
-            half4 r4[MC][4];
-#pragma unroll
-            for (int j = 0; j < MC; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) b4[j][g] = *reinterpret_cast<const floatx4*>(bias + co_[j][g]);
-            if (has_res) {
-#pragma unroll
-                for (int j = 0; j < MC; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) r4[j][g] = *reinterpret_cast<const half4*>(p.res + ridx + co_[j][g]);
-            }
 #pragma unroll
             for (int j = 0; j < MC; ++j) {
+                int co_[4];
+                bool cok[4];
+                floatx4 b4[4], s4[4];
+                half4 r4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                    cok[g] = co < p.Cout;
+                    co_[g] = cok[g] ? co : 0;
+                    b4[g] = *reinterpret_cast<const floatx4*>(bias + co_[g]);
+                }
+                if (prelu) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s4[g] = *reinterpret_cast<const floatx4*>(p.slope + co_[g]);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const half4*>(p.res + ridx + co_[g]);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     floatx4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[j][g][e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[g][e];
                     if (has_res) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[j][g][e];
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[g][e];
                     }
                     if (relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     } else if (prelu) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[j][g][e];
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[g][e];
                     }
-                    if (mok && cok[j][g]) {
+                    if (mok && cok[g]) {
                         if (out32) {
-                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase + co_[j][g]) = v;
+                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase + co_[g]) = v;
                         } else {
                             half4 h;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + obase + co_[j][g]) = h;
+                            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + obase + co_[g]) = h;
                         }
                     }
                 }
+                sched_fence();
             }
         }
     }
+#undef DMA_ALL
 #undef DMA_RANGE
 #undef DMA_PIECE
 }
 
-template <int TP, int TC, int WP, int WC, bool SMALL>
+template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
 static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = CONV_NS * (TP + TC) * 128;
+    const int lds = NS * (TP + TC) * 128;
     static bool attr_set[64] = {};
-    auto kern = conv_mfma_kernel<TP, TC, WP, WC, SMALL>;
+    auto kern = conv_mfma_kernel<TP, TC, WP, WC, NS, NW, SMALL>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -385,16 +428,13 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     }
     const long ntiles = (long)p.n_ptiles * p.n_ctiles;
     if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
-    static int n_cu[64] = {};
-    if (!n_cu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // persistent: one workgroup per CU (the 144 KiB ring allows exactly one), each walks a
+    const int ncu = device_cu_count(dev);
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    // persistent: as many workgroups per CU as the LDS ring allows (1 or 2), each walks a
     // contiguous range of tiles
-    const unsigned grid = (unsigned)(ntiles < n_cu[dev] ? ntiles : n_cu[dev]);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CONV_NW * 64), lds, stream, p);
+    const long slots = (long)ncu * (lds <= 80 * 1024 ? 2 : 1);
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -428,10 +468,19 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if ((p.flags & FRP_FLAG_RES_UP2) && (!p.res || p.Hr * 2 != p.Ho || p.Wr * 2 != p.Wo)) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.bias || !p.out) return hipErrorInvalidValue;
     if (p.act == FRP_ACT_PRELU && !p.slope) return hipErrorInvalidValue;
+    // Tile selection (measured on MI355X, tools/conv_bench.py):
+    //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one
+    //               workgroup per CU).  Two independent 4-wave 128x128 groups per CU (2-slot
+    //               rings) were 20-25 % slower; a 128x64 per-wave tile does not fit 256 VGPRs.
+    //               dbg 16 (conv_bench only) selects the 4-wave variant for A/B runs.
+    //   Cout <= 64: 256 x 64, 8 waves (32x64 each), 3-slot ring.
+    const int force = p.dbg >> 4;
     if (p.Cout > 64) {
-        return small ? launch_cfg<256, 128, 4, 2, true>(p, stream) : launch_cfg<256, 128, 4, 2, false>(p, stream);
+        if (force == 1)
+            return small ? launch_cfg<128, 128, 2, 2, 2, 4, true>(p, stream) : launch_cfg<128, 128, 2, 2, 2, 4, false>(p, stream);
+        return small ? launch_cfg<256, 128, 4, 2, 3, 8, true>(p, stream) : launch_cfg<256, 128, 4, 2, 3, 8, false>(p, stream);
     } else {
-        return small ? launch_cfg<256, 64, 8, 1, true>(p, stream) : launch_cfg<256, 64, 8, 1, false>(p, stream);
+        return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
     }
 }
 

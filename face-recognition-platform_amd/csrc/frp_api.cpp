@@ -935,7 +935,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         p.res = with_res ? (const _Float16*)dr.p : nullptr; p.out = dout.p;
         p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
         p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32);
-        p.dbg = (flags >> 8) & 15;
+        p.dbg = (flags >> 8) & 0xff;
         for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, h->stream);   // warm-up
         if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
         for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_conv(p, h->stream);

@@ -29,7 +29,7 @@ SHAPES = [
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 1: no DMA in the k-loop, 2: no MFMA/LDS reads
+    dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 16: force the large tile, 32: force the medium tile
     eng = native.Engine(0)
     tot = 0.0
     for (name, N, H, W, Cin, Cout, k, s, act, flags, res, cnt) in SHAPES:
