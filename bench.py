@@ -24,6 +24,19 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_conv_traffic_per_launch(launches_per_step):
+    """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r1/pmc_traffic_v2.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
+    in separate passes as the microarch guide prescribes).  None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v2.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return round(t["conv_traffic_bytes_per_step"] / max(1, launches_per_step))
+    except Exception:
+        return None
+
+
 def synth_frames(B, H, W, K, seed):
     """low-amplitude noise background (mean 110, sigma 12) + K planted face blobs."""
     rng = np.random.default_rng(seed)
@@ -184,7 +197,8 @@ def main():
                                               "ms_l2norm", "ms_match")}},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM conv, all detector+embedder launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": pmc_conv_traffic_per_launch(launches // max(1, args.steps)),
                          "launches_per_step": launches // max(1, args.steps),
                          "avg_launch_us": round(conv_ms * 1e3 / max(1, launches), 2),
                          "algorithmic_gflop_per_step": round(conv_flops / args.steps / 1e9, 1),

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -126,11 +127,11 @@ void rec(frp_handle* h, int which) {
 }
 
 // Plan + run one conv program.  in dims: [batch, H, W, in_ch] already written to bufs[in_buf].
-int plan_net(frp_handle* h, Net& net, int batch, int H, int W) {
+int plan_net(frp_handle* h, Net& net, int batch, int H, int W, bool skip_input = false) {
     net.dims.assign(net.n_bufs, TensorDims());
     std::vector<size_t> need(net.n_bufs, 0);
     net.dims[net.in_buf] = {H, W, net.in_ch, false};
-    need[net.in_buf] = (size_t)batch * H * W * net.in_ch * 2;
+    need[net.in_buf] = skip_input ? 0 : (size_t)batch * H * W * net.in_ch * 2;
     for (const frp_conv_op& op : net.ops) {
         TensorDims in = net.dims[op.in_buf];
         if (in.c == 0) return fail(h, FRP_ERR_BLOB, "program reads an unwritten buffer");
@@ -146,16 +147,40 @@ int plan_net(frp_handle* h, Net& net, int batch, int H, int W) {
         net.dims[op.out_buf] = out;
         need[op.out_buf] = std::max(need[op.out_buf], (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : 2));
     }
-    for (int i = 0; i < net.n_bufs; ++i) FRPCHK(ensure(h, net.bufs[i], need[i]));
+    for (int i = 0; i < net.n_bufs; ++i)
+        if (need[i]) FRPCHK(ensure(h, net.bufs[i], need[i]));
     return FRP_OK;
 }
 
-int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches) {
+// first detector op as the fused u8 stem (no NHWC8 blob)?
+bool stem_fusable(const Net& net) {
+    if (net.ops.empty()) return false;
+    const frp_conv_op& op = net.ops[0];
+    return op.in_buf == net.in_buf && op.cin == 8 && op.cout == 32 && op.ksize == 3 && op.stride == 2 &&
+           op.act == FRP_ACT_RELU && op.res_buf < 0 && (op.flags & ~0) == 0 && (op.real_ch & 0xffff) == 3;
+}
+
+int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr) {
     // dims are re-derived while walking (physical buffers are reused by several tensors)
     std::vector<TensorDims> d(net.n_bufs);
     d[net.in_buf] = {H, W, net.in_ch, false};
     const char* wbase = (const char*)h->wdata.p;
+    bool first = true;
     for (const frp_conv_op& op : net.ops) {
+        if (first && stem) {
+            first = false;
+            StemParams sp = *stem;
+            sp.w = (const _Float16*)(wbase + op.w_off);
+            sp.bias = (const float*)(wbase + op.bias_off);
+            sp.out = (_Float16*)net.bufs[op.out_buf].p;
+            hipError_t e = launch_stem_u8(sp, h->stream);
+            if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_stem_u8: ") + hipGetErrorString(e));
+            d[op.out_buf] = {sp.Ho, sp.Wo, 32, false};
+            *flops += 2.0 * batch * sp.Ho * sp.Wo * 9.0 * 3 * 32;
+            *launches += 1;
+            continue;
+        }
+        first = false;
         TensorDims in = d[op.in_buf];
         if (op.flags & FRP_FLAG_FLATTEN) in = {1, 1, in.h * in.w * in.c, false};
         ConvParams p{};
@@ -247,13 +272,27 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
     if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
     if (K <= 0 || K > FRP_MAX_FACES_CAP) return fail(h, FRP_ERR_INVALID, "max_faces out of range");
     const int B = h->rB, Hc = h->canvas_h, Wc = h->canvas_w;
-    FRPCHK(plan_net(h, h->det, B, Hc, Wc));
+    // The detector's first layer reads the u8 frames directly (fused normalise + conv) whenever
+    // the program starts with the standard 3x3 s2 3->32 stem; FRP_NO_FUSED_STEM=1 keeps the
+    // two-kernel path (preprocess to an NHWC8 blob, then the generic conv) for A/B runs.
+    const bool fused = stem_fusable(h->det) && !getenv("FRP_NO_FUSED_STEM");
+    FRPCHK(plan_net(h, h->det, B, Hc, Wc, fused));
     FRPCHK(ensure_results(h, B, K));
-    hipError_t e = launch_preprocess((const uint8_t*)h->frames.p, B, h->rH, h->rW, (long)h->rW * 3, (long)h->rH * h->rW * 3,
-                                     (_Float16*)h->det.bufs[h->det.in_buf].p, Hc, Wc, (flags & FRP_FLAG_RGB) ? 1 : 0, h->stream);
-    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    StemParams sp{};
+    if (fused) {
+        sp.frames = (const uint8_t*)h->frames.p;
+        sp.B = B; sp.H = h->rH; sp.W = h->rW;
+        sp.row_stride = (long)h->rW * 3; sp.frame_stride = (long)h->rH * h->rW * 3;
+        sp.Hc = Hc; sp.Wc = Wc; sp.Ho = Hc / 2; sp.Wo = Wc / 2;
+        sp.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
+    } else {
+        e = launch_preprocess((const uint8_t*)h->frames.p, B, h->rH, h->rW, (long)h->rW * 3, (long)h->rH * h->rW * 3,
+                              (_Float16*)h->det.bufs[h->det.in_buf].p, Hc, Wc, (flags & FRP_FLAG_RGB) ? 1 : 0, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
+    }
     rec(h, EV_PRE);
-    FRPCHK(run_net(h, h->det, B, Hc, Wc, &h->ctr.det_conv_flops, &h->ctr.det_conv_launches));
+    FRPCHK(run_net(h, h->det, B, Hc, Wc, &h->ctr.det_conv_flops, &h->ctr.det_conv_launches, fused ? &sp : nullptr));
     rec(h, EV_DET);
     DecodeParams dp{};
     for (int l = 0; l < 3; ++l) {

@@ -39,6 +39,20 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
 hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,
                              _Float16* out, int Hc, int Wc, int rgb_in, hipStream_t stream);
 
+// K1+K2 fused detector stem: u8 frames -> conv3x3 s2 (3->32) + bias + ReLU, fp16 NHWC
+struct StemParams {
+    const uint8_t* frames;   // [B,H,W,3] u8
+    int B, H, W;
+    long row_stride, frame_stride;
+    int Hc, Wc;              // letterbox canvas (multiples of 32)
+    int Ho, Wo;              // Hc/2, Wc/2
+    int rgb_in;
+    const _Float16* w;       // folded [32][3][3][8] fp16 (channels R,G,B,0..)
+    const float* bias;       // [32]
+    _Float16* out;           // [B,Ho,Wo,32]
+};
+hipError_t launch_stem_u8(const StemParams& p, hipStream_t stream);
+
 // K3: decode + candidate select + sort + NMS, one workgroup per frame
 struct DecodeParams {
     const _Float16* head[3];   // per stride [B, H_l, W_l, 32]
