@@ -119,7 +119,10 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
             sys.exit(2)
     dist = None
-    if world > 1:
+    # FRP_FORCE_DIST=1 exercises the RCCL path (process group, gallery all-gather, device hand-off)
+    # even with one rank -- used to rehearse the multi-GPU code on a one-GPU box
+    use_dist = world > 1 or os.environ.get("FRP_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -133,7 +136,7 @@ def main():
     eng.load_weights(blob)
 
     # gallery: each rank owns rows [r*N/R, (r+1)*N/R); one RCCL all-gather replicates it (setup only)
-    if world > 1:
+    if use_dist:
         import torch
         from frp_amd import dist as fdist
         fdist.allgather_gallery_into_engine(eng, N, lambda first, cnt: gallery_rows(N, first, cnt), local_rank)

@@ -401,7 +401,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
                         }
                     }
                 }
-                sched_fence();
             }
         }
     }
