@@ -111,6 +111,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    # Everything except the final JSON line goes to stderr: RCCL prints a version banner on the
+    # stdout file descriptor when its communicator is created.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,7 +215,7 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(raw, frames, K, N, args.cpu_frames)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

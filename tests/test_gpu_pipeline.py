@@ -109,3 +109,49 @@ def test_no_faces_and_no_gallery(engine):
     assert o["counts"][0] == 0 and np.all(o["emb"] == 0) and np.all(o["match_idx"] == -1)
     o = engine.process_frames(frames, max_faces=5, flags=1)      # faces but empty gallery
     assert o["counts"][0] == 5 and np.all(o["match_idx"] == -1)
+
+
+def test_full_size_properties_1080p_r100(engine):
+    """BASELINE-sized run (32 x 1080p frames, full detector, IResNet-100, 100k gallery) checked
+    through size-independent properties: exact face counts, unit embeddings, idempotence,
+    frame-permutation equivariance, planted identities found at cosine ~1, tie-free top-1
+    consistent with a float64 recomputation on a sample."""
+    from frp_amd import native
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (3, 13, 30, 3))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(2025)
+    B, H, W, K = 32, 1080, 1920, 10
+    frames = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    G = rng.standard_normal((100_000, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    engine.gallery_set(G)
+    a = engine.process_frames(frames, max_faces=K, flags=native.FLAG_FORCED_K)
+    assert np.all(a["counts"] == K)
+    assert np.abs(np.linalg.norm(a["emb"], axis=-1) - 1).max() < 1e-4
+    assert np.all(np.diff(a["scores"], axis=1) <= 0)                      # detector order = score descending
+    b = engine.process_frames(frames, max_faces=K, flags=native.FLAG_FORCED_K)
+    for key in ("boxes", "kps", "scores", "emb", "match_idx", "match_cos"):
+        assert np.array_equal(a[key], b[key]), key                          # idempotent / deterministic
+    perm = rng.permutation(B)
+    c = engine.process_frames(frames[perm], max_faces=K, flags=native.FLAG_FORCED_K)
+    for key in ("boxes", "kps", "emb", "match_idx"):
+        assert np.array_equal(a[key][perm], c[key]), key                    # frames never interact
+    # top-1 against float64 on a sample of faces (fp16 gallery: allow only near-ties to differ)
+    sample = a["emb"][::8, ::3].reshape(-1, 512).astype(np.float64)
+    S = sample @ G.T.astype(np.float64)
+    ref_idx = S.argmax(1)
+    got_idx = a["match_idx"][::8, ::3].reshape(-1)
+    got_cos = a["match_cos"][::8, ::3].reshape(-1)
+    ref_cos = S.max(1)
+    assert np.abs(got_cos - ref_cos).max() < 1e-3
+    differ = got_idx != ref_idx
+    assert np.all(np.abs(S[np.arange(len(S)), got_idx] - ref_cos)[differ] < 5e-4)
+    # plant the produced embeddings as identities: every face must find itself
+    rows = rng.choice(100_000, size=B * K, replace=False)
+    G2 = G.copy()
+    G2[rows] = a["emb"].reshape(-1, 512)
+    engine.gallery_set(G2)
+    d = engine.process_frames(frames, max_faces=K, flags=native.FLAG_FORCED_K)
+    assert np.array_equal(d["match_idx"].reshape(-1), rows)
+    assert d["match_cos"].min() > 0.999
+    engine.gallery_set(np.zeros((0, 512), np.float32))
