@@ -425,15 +425,24 @@ class FaceService:
 
     # ------------------------------------------------------------------ streaming entry points (new)
     def process_frames(self, frames_bgr: np.ndarray, max_faces: int = 10, threshold: Optional[float] = None,
-                       det_thresh: Optional[float] = None) -> List[List[Dict[str, Any]]]:
+                       det_thresh: Optional[float] = None, all_matches: bool = False) -> List[List[Dict[str, Any]]]:
         """The live-loop body of routes/camera.py:225-259 for a batch of BGR frames, with the
         per-face compare + filter reduced to a fused device top-1: per frame a list of
-        {bbox, kps, score, embedding, target, distance, cosine, confidence, match}."""
+        {bbox, kps, score, embedding, target, distance, cosine, confidence, match}.
+        all_matches=True additionally lists EVERY enrolled target within both the service
+        tolerance and `threshold` (the reference's exact loop semantics, camera.py:246-256: a face
+        can hit several near-duplicate identities), ascending by distance, under "matches"."""
         tol = self.tolerance if threshold is None else min(self.tolerance, threshold)   # camera.py:250
         have_gallery = len(self.ENCODINGS) > 0
         out = self._eng().process_frames(frames_bgr, max_faces=max_faces,
                                          det_thresh=DET_THRESH if det_thresh is None else det_thresh, nms_iou=NMS_IOU,
                                          flags=0 if have_gallery else native.FLAG_NO_MATCH)
+        all_d = names = None
+        if all_matches and have_gallery and int(out["counts"].sum()) > 0:
+            Q = np.concatenate([out["emb"][b, :int(c)] for b, c in enumerate(out["counts"])])
+            names = self.ENCODINGS.names()
+            all_d = cos_to_distance(self._eng().match_scores(Q)[:, self.ENCODINGS.rows_of(names)])
+        f_idx = 0
         result = []
         n_total = 0
         for b in range(out["counts"].shape[0]):
@@ -448,6 +457,15 @@ class FaceService:
                               "distance": d, "cosine": cos if row >= 0 else None,
                               "confidence": confidence_level(d) if d is not None else None,
                               "match": bool(d is not None and d <= tol)})
+                if all_matches:
+                    hits = []
+                    if all_d is not None:
+                        dd = all_d[f_idx]
+                        order = np.argsort(dd, kind="stable")          # compare_faces sorts ascending (:432)
+                        hits = [{"target": names[i], "distance": float(dd[i]), "confidence": confidence_level(float(dd[i]))}
+                                for i in order if dd[i] <= tol]
+                    faces[-1]["matches"] = hits
+                f_idx += 1
             n_total += len(faces)
             result.append(faces)
         with self._metrics_lock:
