@@ -179,11 +179,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _Float16* __restrict__ emb16, int M, int D) {
+__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _Float16* __restrict__ emb16, int M, int D,
+                                                      const float* __restrict__ partials, int ksplit, const float* __restrict__ bias) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     float* e = emb + (long)row * D;
+    if (partials) {                       // split-K FC: reduce the slabs (+ folded bias) first
+        for (int i = lane; i < D; i += 64) {
+            float v = bias[i];
+            for (int s = 0; s < ksplit; ++s) v += partials[((long)s * M + row) * D + i];
+            e[i] = v;
+        }
+    }
     float ss = 0.f;
     for (int i = lane; i < D; i += 64) ss += e[i] * e[i];
     ss = wave_sum(ss);
@@ -195,9 +203,11 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _F
     }
 }
 
-hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream) {
+hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream, const float* partials, int ksplit,
+                         const float* bias) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(l2norm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, emb, emb16, M, D);
+    if (partials && (ksplit <= 0 || !bias)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, emb, emb16, M, D, partials, ksplit, bias);
     return hipGetLastError();
 }
 

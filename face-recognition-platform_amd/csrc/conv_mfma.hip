@@ -100,11 +100,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
 
     // Persistent workgroup: a contiguous range of tiles (tile = ptile * n_ctiles + ctile, so the
     // cout tiles of one pixel tile follow each other on the same CU and L2).
-    const int n_tiles = p.n_ptiles * p.n_ctiles;
+    // With split-K (p.ksplit > 1, used for the FC whose M is tiny and K huge) a "tile" below is a
+    // (tile, k-slice) pair: slice s covers k-steps [s*nk, (s+1)*nk) and writes raw fp32 partial
+    // sums to a workspace slab that a finalize kernel reduces.
+    const int n_tiles = p.n_ptiles * p.n_ctiles * p.ksplit;
     const int t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
     const int t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
     if (t0 >= t1) return;
-    const int nk = p.nk;
+    const int nk = p.nk / p.ksplit;            // k-steps per (tile, slice); launch_conv makes it exact
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -123,7 +126,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     int kh = 0, kw = 0, cb = 0;               // aligned path: uniform (tap, 64-channel block) walk
     const int cpt = p.Cin >> 6;
     int it = t0, iks = 0, ibuf = 0;           // issue cursor: tile, k-step, ring slot
-    auto setup_issue_tile = [&](int tile) {
+    int iks_base = 0;                         // first k-step of the issue cursor's slice
+    auto setup_issue_tile = [&](int vtile) {
+        const int tile = vtile / p.ksplit;
+        iks_base = (vtile - tile * p.ksplit) * nk;
         const int ptile = tile / p.n_ctiles;
         const int m0i = ptile * TP;
         const int c0i = (tile - ptile * p.n_ctiles) * TC;
@@ -157,7 +163,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             const int co = c0i + (i * NW + wave) * 8 + lrow;
             woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
         }
-        kh = kw = cb = 0;
+        if constexpr (!SMALL) {                  // start of the slice in the (tap, channel block) walk
+            const int tap = iks_base / cpt;
+            cb = iks_base - tap * cpt;
+            kh = tap / p.KS;
+            kw = tap - kh * p.KS;
+        }
     };
 
     // One stage = LPS DMA pieces per wave.  `prep_stage` computes the per-lane source offsets of
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     unsigned st_bit = 0, st_wadd = 0;
     bool st_kin = true;
     auto prep_stage = [&]() {
-        const int ks = iks;
+        const int ks = iks_base + iks;
         if constexpr (!SMALL) {
             st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
             st_bit = 1u << (kh * 3 + kw);
@@ -333,9 +344,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
         // (or fp32) stores straight from registers while the next tile's first stages are already
         // in flight.  All bias / slope / residual loads of a pixel row are issued back to back
         // from clamped (always valid) addresses before any is consumed; stores are predicated.
-        const int ptile = ct / p.n_ctiles;
+        const int ctile_id = ct / p.ksplit;
+        const int ptile = ctile_id / p.n_ctiles;
         const int m0 = ptile * TP;
-        const int c0 = (ct - ptile * p.n_ctiles) * TC;
+        const int c0 = (ctile_id - ptile * p.n_ctiles) * TC;
+        if (p.ksplit > 1) {                       // raw fp32 partial sums -> workspace slab of this slice
+            float* slab = reinterpret_cast<float*>(p.out) + (long)(ct - ctile_id * p.ksplit) * p.M * p.Cout;
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+                const int m = m0 + prow0 + i * 32 + fr;
+#pragma unroll
+                for (int j = 0; j < MC; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                        if (m < p.M && co < p.Cout) {
+                            floatx4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                            *reinterpret_cast<floatx4*>(slab + (long)m * p.Cout + co) = v;
+                        }
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
             const int mraw = m0 + prow0 + i * 32 + fr;
@@ -425,7 +457,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    const long ntiles = (long)p.n_ptiles * p.n_ctiles;
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles * p.ksplit;
     if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
@@ -451,6 +483,9 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     p.M = (int)M;
     p.Ktot = p.KS * p.KS * p.Cin;
     p.nk = (p.Ktot + 63) / 64;
+    if (p.ksplit < 1) p.ksplit = 1;
+    if (p.ksplit > 1 && (p.nk % p.ksplit != 0 || !(p.flags & FRP_FLAG_OUT_F32) || p.res || (p.Cin & 63)))
+        return hipErrorInvalidValue;             // split-K: exact slices, fp32 slabs, aligned path only
     // buffer descriptors carry 32-bit sizes and the kernel does signed 32-bit offset math
     const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * p.Ktot * 2;
     if (xb >= 0x7fffffffL || wb >= 0x7fffffffL) return hipErrorInvalidValue;
@@ -483,6 +518,20 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         // per wave measured 10 % slower: these 9-step layers are bound by per-tile overheads)
         return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
     }
+}
+
+// Split-K factor for a skinny GEMM-shaped conv (the 25088 -> 512 FC: 8 output tiles but 392
+// k-steps): the largest divisor of nk that keeps >= 8 k-steps per slice and does not exceed the
+// CU count in (tile, slice) pairs.  1 = no split.
+int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_cu) {
+    if (!(flags & FRP_FLAG_OUT_F32) || has_res || (Ktot & 63)) return 1;
+    const int nk = Ktot / 64;
+    const long tiles = (long)((M + 255) / 256) * ((Cout + 127) / 128);
+    if (tiles * 4 > n_cu || nk < 64) return 1;
+    int best = 1;
+    for (int s = 2; s <= nk / 8; ++s)
+        if (nk % s == 0 && tiles * s <= n_cu) best = s;
+    return best;
 }
 
 }  // namespace frp

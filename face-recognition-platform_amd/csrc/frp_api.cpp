@@ -58,7 +58,9 @@ struct frp_handle {
     int rB = 0, rH = 0, rW = 0;
     int canvas_h = 0, canvas_w = 0;
     // per-call results (device)
-    DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch;
+    DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws;
+    int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them
+    const float* fc_bias = nullptr;
     int last_B = 0, last_K = 0, last_nfaces = 0;
     bool last_matched = false;
     int32_t* h_nfaces = nullptr;   // pinned
@@ -194,6 +196,27 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
         p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
         if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
+        // skinny fp32-output GEMM (the FC): split K over the CUs; the slabs are reduced (+bias) by
+        // the l2norm kernel that follows
+        h->fc_ksplit = 0;
+        if ((op.flags & FRP_FLAG_OUT_F32) && &op == &net.ops.back() && !getenv("FRP_NO_SPLITK")) {
+            int dev = 0, ncu = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ncu = prop.multiProcessorCount;
+            const int ks = conv_pick_ksplit(batch * ((in.h + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1) *
+                                                ((in.w + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1),
+                                            op.cout, op.ksize * op.ksize * op.cin, op.flags, op.res_buf >= 0, ncu);
+            if (ks > 1) {
+                const size_t slab = (size_t)ks * batch * op.cout * 4;   // 1x1 output per image for the FC shape
+                if (in.h == 1 && in.w == 1 && ensure(h, h->splitk_ws, slab) == FRP_OK) {
+                    p.ksplit = ks;
+                    p.out = h->splitk_ws.p;
+                    h->fc_ksplit = ks;
+                    h->fc_bias = p.bias;
+                }
+            }
+        }
         hipError_t e = launch_conv(p, h->stream);
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_conv: ") + hipGetErrorString(e));
         const int pad = op.ksize / 2;
@@ -327,7 +350,8 @@ int run_embed(frp_handle* h, int n) {
     const int mpad = round_up(n, 32);
     FRPCHK(ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2));
     HIPCHK(h, hipMemsetAsync(h->q16.p, 0, (size_t)mpad * FRP_EMB_DIM * 2, h->stream));
-    hipError_t e = launch_l2norm((float*)h->emb.bufs[h->hdr.emb_out_buf].p, (_Float16*)h->q16.p, n, FRP_EMB_DIM, h->stream);
+    hipError_t e = launch_l2norm((float*)h->emb.bufs[h->hdr.emb_out_buf].p, (_Float16*)h->q16.p, n, FRP_EMB_DIM, h->stream,
+                                 h->fc_ksplit > 1 ? (const float*)h->splitk_ws.p : nullptr, h->fc_ksplit, h->fc_bias);
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("l2norm: ") + hipGetErrorString(e));
     rec(h, EV_L2);
     return FRP_OK;
@@ -539,7 +563,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
-                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->gallery};
+                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->gallery};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);

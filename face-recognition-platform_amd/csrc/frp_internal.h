@@ -27,6 +27,7 @@ struct ConvParams {
     int N, H, W, Cin, Cout, KS, stride;
     int act, flags;
     int Hr, Wr;             // residual spatial dims (RES_UP2)
+    int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums
     int dbg;                // tuning ablations (conv_bench only): 1 = no DMA in the loop, 2 = no MFMA
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
@@ -87,8 +88,12 @@ hipError_t launch_chips_to_blob(const uint8_t* chips, int M, _Float16* out, hipS
 hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int32_t* face_slot, int32_t* n_faces,
                                 hipStream_t stream);
 
-// K5 tail: row-wise L2 normalisation of [M,512] fp32 (in place) + fp16 copy for the matcher
-hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream);
+// K5 tail: row-wise L2 normalisation of [M,512] fp32 (in place) + fp16 copy for the matcher.
+// With `partials` (split-K FC): emb[m][c] = sum_s partials[s][m][c] + bias[c] first.
+hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream,
+                         const float* partials = nullptr, int ksplit = 0, const float* bias = nullptr);
+// choose a split factor for a conv (1 = none): small M, long K, fp32 output
+int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_cu);
 // gallery upload: fp32 rows -> unit fp16 rows
 hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
 
