@@ -58,7 +58,7 @@ struct frp_handle {
     int rB = 0, rH = 0, rW = 0;
     int canvas_h = 0, canvas_w = 0;
     // per-call results (device)
-    DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws;
+    DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws, dense_logits;
     int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them
     const float* fc_bias = nullptr;
     int last_B = 0, last_K = 0, last_nfaces = 0;
@@ -332,6 +332,12 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
     dp.nms_iou = forced ? 2.0f : nms_iou;
     dp.boxes = (float*)h->boxes.p; dp.kps = (float*)h->kps.p; dp.scores = (float*)h->scores.p;
     dp.anchor = (int32_t*)h->anchor.p; dp.counts = (int32_t*)h->counts.p;
+    {
+        size_t anchors = 0;
+        for (int l = 0; l < 3; ++l) anchors += (size_t)dp.hl[l] * dp.wl[l] * 2;
+        FRPCHK(ensure(h, h->dense_logits, (size_t)B * anchors * 2));
+        dp.logits = (_Float16*)h->dense_logits.p;
+    }
     e = launch_decode_nms(dp, h->stream);
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("decode_nms: ") + hipGetErrorString(e));
     e = launch_compact_faces((const int32_t*)h->counts.p, B, K, (int32_t*)h->face_slot.p, (int32_t*)h->nfaces.p, h->stream);
@@ -563,7 +569,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
-                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->gallery};
+                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->gallery};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
@@ -798,7 +804,11 @@ int frp_decode_heads(frp_handle* h, const void* head8, const void* head16, const
         dp.nms_iou = forced ? 2.0f : nms_iou;
         dp.boxes = (float*)h->boxes.p; dp.kps = (float*)h->kps.p; dp.scores = (float*)h->scores.p;
         dp.anchor = (int32_t*)h->anchor.p; dp.counts = (int32_t*)h->counts.p;
-        hipError_t e = launch_decode_nms(dp, h->stream);
+        size_t anchors = 0;
+        for (int l = 0; l < 3; ++l) anchors += (size_t)dp.hl[l] * dp.wl[l] * 2;
+        rc = ensure(h, h->dense_logits, (size_t)B * anchors * 2);
+        dp.logits = (_Float16*)h->dense_logits.p;
+        hipError_t e = rc == FRP_OK ? launch_decode_nms(dp, h->stream) : hipSuccess;
         if (e != hipSuccess) rc = fail(h, FRP_ERR_HIP, std::string("decode_nms: ") + hipGetErrorString(e));
     }
     const size_t s = (size_t)B * max_faces;

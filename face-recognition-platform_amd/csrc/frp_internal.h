@@ -65,6 +65,7 @@ struct DecodeParams {
     float* scores;    // [B, max_faces]
     int32_t* anchor;  // [B, max_faces]
     int32_t* counts;  // [B]
+    _Float16* logits; // scratch [B, anchors]: dense copy of the anchor logits
 };
 hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream);
 
