@@ -57,6 +57,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 // (device-only constructs must live in __device__ functions: written directly in the __global__
 // template body they make the HOST pass drop the kernel stub without a diagnostic)
 __device__ __forceinline__ void keep_alive(floatx16 v) { asm volatile("" ::"v"(v)); }
+// Half-wave exchange: lane<32 ends up with this pixel's couts [lo | upper lane's lo] (16 contiguous
+// bytes), lane>=32 with [lower lane's hi | hi]: two 8-byte stores per lane become one 16-byte store
+// (the epilogue store tail is issue-bound, not bandwidth-bound).
+__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// diagnostic stamps (conv_bench only, p.stamps != null): 100 MHz wall clock per workgroup phase,
+// written to a buffer nothing else reads
+__device__ __forceinline__ void stamp(unsigned long long* buf, int slot) {
+    if (buf && threadIdx.x == 0) buf[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
 // keeps hipcc from hoisting the loads of every epilogue slice above the first one (which
 // would need several hundred live registers)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
@@ -69,6 +82,15 @@ static int device_cu_count(int dev) {
         n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     return n_cu[dev];
+}
+
+// q = m / d, r = m % d for 0 <= m < 2^24 via a float reciprocal and one correction step
+// (an integer division costs ~40 instructions; the prologue needs two per pixel row)
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
+    q = (int)((float)m * inv_d);
+    r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
 }
 
 template <int N>
@@ -120,6 +142,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // logical 16-B chunk of this lane
     const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
     int xoff[XI];          // byte offset of (n, iy0, ix0, c=0) + this lane's chunk; wraps at the border
     unsigned tapmask[XI];  // bit kh*3+kw set <=> that tap of this pixel row lies inside the image
     unsigned woff[WI];     // byte offset of (cout row, k=chunk); rows >= Cout are out of range -> zeros
@@ -139,10 +162,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             unsigned mask = 0;
             int off = 0;
             if (m < p.M) {
-                const int n = m / HoWo;
-                const int rem = m - n * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
                 const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
                 off = (((n * p.H + y0) * p.W + x0) * p.Cin) * 2;
                 unsigned ym = 0, xm = 0;      // 3-bit validity of y0+{0,1,2}, x0+{0,1,2}
@@ -261,8 +283,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     // DMA pieces fired after MFMA group kk: an even split of LPS over the 4 sub-steps
     constexpr int Q1 = (LPS + 3) / 4, Q2 = (LPS + 1) / 2, Q3 = (3 * LPS + 3) / 4;
 
+    // ---------------- per-tile epilogue parameters in LDS (behind the ring): bias (1 or 9 classes) and
+    // PReLU slope of this tile's TC couts.  They are fetched at the start of the tile's first k-step and
+    // written at its end, so the epilogue reads them with short LDS latencies instead of serialising
+    // on global loads.
+    float* lds_bias = reinterpret_cast<float*>(smem + NS * STAGE);       // [9][TC] (class-major)
+    float* lds_slope = lds_bias + 9 * TC;                                  // [TC]
+    constexpr int PPT = (9 * TC + NW * 64 - 1) / (NW * 64);               // bias values per thread
+    float pb[PPT], ps = 0.f;
+    const bool border_ = p.flags & FRP_FLAG_BORDER_BIAS;
+    auto fetch_params = [&](int vtile) {
+        const int tile = vtile / p.ksplit;
+        const int c0p = (tile % p.n_ctiles) * TC;
+        const int nb = (border_ ? 9 : 1) * TC;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            const int cls = idx / TC, co = c0p + (idx - cls * TC);
+            pb[q] = (idx < nb && co < p.Cout) ? p.bias[(long)cls * p.Cout + co] : 0.f;
+        }
+        if (p.act == FRP_ACT_PRELU && t < TC) ps = (c0p + t < p.Cout) ? p.slope[c0p + t] : 0.f;
+    };
+    auto store_params = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            if (idx < 9 * TC) lds_bias[idx] = pb[q];
+        }
+        if (t < TC) lds_slope[t] = ps;
+    };
+
     // ---------------- the stage stream: NS-slot ring, one barrier per k-step, continuous over tiles
     const int total = (t1 - t0) * nk;          // stages this workgroup consumes
+    stamp(p.stamps, 0);
     setup_issue_tile(t0);
     int issued = 0;
 #pragma unroll
@@ -282,6 +335,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     const bool prelu = p.act == FRP_ACT_PRELU;
     const bool relu = p.act == FRP_ACT_RELU;
 
+    stamp(p.stamps, 1);
     for (int ct = t0; ct < t1; ++ct) {
 #pragma unroll
         for (int i = 0; i < MP; ++i)
@@ -289,6 +343,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             for (int j = 0; j < MC; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        if (ct == t0) stamp(p.stamps, 2);
 
         for (int ks = 0; ks < nk; ++ks) {
             // The stage to consume has landed for THIS wave once only the newer stages may still be
@@ -302,6 +357,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XB;
             const int nbuf = ibuf;
+            if (ks == 0 && p.ksplit == 1) fetch_params(ct);   // every wave is past the previous epilogue here
             read_frags(xs, ws, 0, 0);
             if (issued < total) {                       // uniform; false only for the last PRE steps
                 prep_stage();
@@ -335,9 +391,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
                     read_frags(xs, ws, 3, 0); mfma_group(0);
                 }
             }
+            if (ks == 0 && p.ksplit == 1) store_params();
             ++consumed;
             buf = buf == NS - 1 ? 0 : buf + 1;
+            if (ct == t0 && ks == 0) stamp(p.stamps, 3);      // first k-step done (includes the first DMA latency)
         }
+        if (ct == t0) stamp(p.stamps, 4);                      // first tile's k-loop done
 
         // ---------------- epilogue of tile ct (accumulator layout: lane = one pixel, 4 consecutive
         // couts per register group): bias / border-class bias, residual, activation in fp32, fp16
@@ -368,74 +427,96 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             }
             continue;
         }
+        // bias / slope come from the LDS parameter cache; only the residual needs global loads, all
+        // issued up front (32 VGPRs).  Interior tiles (the common case) take a copy of the body with
+        // unconditional stores; ragged tiles clamp the load addresses and predicate the stores.
+        if (nk == 1) __syncthreads();             // params were written in this very k-step
+        auto epilogue_body = [&](auto FULL_T) {
+            constexpr bool FULL = decltype(FULL_T)::value;
+            half4 r4[MP][MC][4];
+            bool mok[MP];
+            long obase[MP];
+            int cls[MP];
 #pragma unroll
-        for (int i = 0; i < MP; ++i) {
-            const int mraw = m0 + prow0 + i * 32 + fr;
-            const bool mok = mraw < p.M;
-            const int m = mok ? mraw : 0;
-            int cls = 0;
-            long ridx = (long)m * p.Cout;
-            if (border || up2) {
-                const int n = m / HoWo;
-                const int rem = m - n * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                if (border) cls = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-                if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
-            }
-            const float* bias = p.bias + (long)cls * p.Cout;
-            const long obase = (long)m * p.Cout;
-#pragma unroll
-            for (int j = 0; j < MC; ++j) {
-                int co_[4];
-                bool cok[4];
-                floatx4 b4[4], s4[4];
-                half4 r4[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                    cok[g] = co < p.Cout;
-                    co_[g] = cok[g] ? co : 0;
-                    b4[g] = *reinterpret_cast<const floatx4*>(bias + co_[g]);
+            for (int i = 0; i < MP; ++i) {
+                const int mraw = m0 + prow0 + i * 32 + fr;
+                mok[i] = FULL || mraw < p.M;
+                const int m = mok[i] ? mraw : 0;
+                long ridx = (long)m * p.Cout;
+                cls[i] = 0;
+                if (border || up2) {
+                    int n, rem, oy, ox;
+                    fast_divmod(m, HoWo, inv_howo, n, rem);
+                    fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                    if (border) cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+                    if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
                 }
-                if (prelu) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) s4[g] = *reinterpret_cast<const floatx4*>(p.slope + co_[g]);
-                }
+                obase[i] = (long)m * p.Cout;
                 if (has_res) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const half4*>(p.res + ridx + co_[g]);
+                    for (int j = 0; j < MC; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                            r4[i][j][g] = *reinterpret_cast<const half4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
+                        }
                 }
+            }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    floatx4 v;
+            for (int i = 0; i < MP; ++i) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[g][e];
-                    if (has_res) {
+                for (int j = 0; j < MC; ++j) {
+                    floatx4 v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[g][e];
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = crow0 + j * 32 + 8 * g + 4 * fh;          // cout inside the tile
+                        const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
+                        if (has_res) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                        } else if (prelu) {
+                            const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
+                        }
                     }
-                    if (relu) {
+                    if (out32) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (prelu) {
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                            if (FULL || (mok[i] && co < p.Cout))
+                                *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
+                        }
+                    } else {
+                        // fp16: exchange between the half-waves so every lane stores 16 contiguous bytes
+                        union { half4 h; unsigned u[2]; } pk[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[g][e];
-                    }
-                    if (mok && cok[g]) {
-                        if (out32) {
-                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase + co_[g]) = v;
-                        } else {
-                            half4 h;
+                        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
-                            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + obase + co_[g]) = h;
+                            for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                            swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                            const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;   // 8 consecutive couts
+                            if (FULL || (mok[i] && co < p.Cout))
+                                *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
+                                    make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
                         }
                     }
                 }
             }
-        }
+        };
+        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}); else epilogue_body(std::false_type{});
+        if (ct == t0) stamp(p.stamps, 5);                      // first tile's epilogue issued
     }
+    stamp(p.stamps, 6);                                        // all tiles done (after the last epilogue's issue)
 #undef DMA_ALL
 #undef DMA_RANGE
 #undef DMA_PIECE
@@ -446,7 +527,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = NS * (TP + TC) * 128;
+    const int lds = NS * (TP + TC) * 128 + 10 * TC * 4;   // operand ring + epilogue parameter cache
     static bool attr_set[64] = {};
     auto kern = conv_mfma_kernel<TP, TC, WP, WC, NS, NW, SMALL>;
     int dev = 0;

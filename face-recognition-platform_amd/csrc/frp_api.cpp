@@ -981,7 +981,7 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
 }
 
 int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
-                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg) {
+                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg, uint64_t* stamps_out) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (!ms_avg || iters <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(h, FRP_ERR_INVALID, "bad bench arguments");
@@ -1009,12 +1009,19 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
         p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32);
         p.dbg = (flags >> 8) & 0xff;
+        DevBuf dst;
+        if (stamps_out && ensure(h, dst, 256 * 8 * 8) == FRP_OK) {
+            (void)hipMemsetAsync(dst.p, 0, 256 * 8 * 8, h->stream);
+            p.stamps = (unsigned long long*)dst.p;
+        }
         for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, h->stream);   // warm-up
         if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
         for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_conv(p, h->stream);
         if (e == hipSuccess) e = hipEventRecord(h->ev[1], h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+        if (e == hipSuccess && stamps_out && p.stamps) e = hipMemcpy(stamps_out, p.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost);
+        release(dst);
     }
     (void)hipStreamSynchronize(h->stream);
     DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout};

@@ -28,6 +28,7 @@ struct ConvParams {
     int act, flags;
     int Hr, Wr;             // residual spatial dims (RES_UP2)
     int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums
+    unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
     int dbg;                // tuning ablations (conv_bench only): 1 = no DMA in the loop, 2 = no MFMA
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;

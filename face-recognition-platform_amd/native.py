@@ -92,7 +92,7 @@ def load_library() -> C.CDLL:
     lib.frp_match.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.frp_match_scores.argtypes = [vp, vp, i32, vp]
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
-    lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float)]
+    lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
     lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
     lib.frp_reset_counters.argtypes = [vp]
@@ -302,10 +302,11 @@ class Engine:
                                             _ptr(res), rh, rw, act, flags, _ptr(out)))
         return out
 
-    def conv_bench(self, N, H, W, Cin, Cout, k=3, stride=1, act=0, flags=0, with_res=False, iters=20) -> float:
+    def conv_bench(self, N, H, W, Cin, Cout, k=3, stride=1, act=0, flags=0, with_res=False, iters=20, stamps=False):
         ms = C.c_float()
-        self._chk(self._lib.frp_conv_bench(self._h, N, H, W, Cin, Cout, k, stride, act, flags, int(with_res), iters, C.byref(ms)))
-        return float(ms.value)
+        st = np.zeros((256, 8), np.uint64) if stamps else None
+        self._chk(self._lib.frp_conv_bench(self._h, N, H, W, Cin, Cout, k, stride, act, flags, int(with_res), iters, C.byref(ms), _ptr(st)))
+        return (float(ms.value), st) if stamps else float(ms.value)
 
     def mfma_peak(self, waves_per_simd=1, iters=20000) -> float:
         t = C.c_float()

@@ -171,7 +171,8 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
 /* tuning hook: average milliseconds of `iters` back-to-back launches of one conv shape on
  * random device-resident operands (HIP events on the handle's stream) */
 int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
-                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg);
+                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg,
+                   uint64_t* stamps_out /* NULL, or [256][8] per-workgroup 100 MHz phase stamps of the last launch */);
 
 /* tuning hook: sustained v_mfma_f32_32x32x16_f16 rate of this device on register operands */
 int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops);
