@@ -229,5 +229,34 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
     return bytes(out)
 
 
+def load_arcface_state_dict(path: str, prefix: str = "emb.") -> Dict[str, np.ndarray]:
+    """Embedder weights from a PyTorch checkpoint in the public arcface_torch `iresnet` naming
+    (conv1.weight, bn1.*, prelu.weight, layer{1..4}.{i}.{bn1,conv1,bn2,prelu,conv2,bn3,downsample.0/1}.*,
+    bn2.*, fc.{weight,bias}, features.*) -> the raw dict `pack_blob` consumes.  No such file exists
+    offline; the layout is exercised on a checkpoint written by the tests."""
+    import torch
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    raw = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        k = k[7:] if k.startswith("module.") else k
+        raw[prefix + k] = v.detach().cpu().float().numpy()
+    return raw
+
+
+def emb_blocks_of(raw: Dict[str, np.ndarray]) -> Tuple[int, int, int, int]:
+    """number of IBasicBlocks per stage present in a raw dict (R50 = (3,4,14,3), R100 = (3,13,30,3))"""
+    out = []
+    for li in (1, 2, 3, 4):
+        n = 0
+        while f"emb.layer{li}.{n}.conv1.weight" in raw:
+            n += 1
+        out.append(n)
+    return tuple(out)
+
+
 def synthetic_blob(seed: int = 7, det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3)) -> bytes:
     return pack_blob(make_synthetic_raw(seed, det_blocks, emb_blocks), det_blocks, emb_blocks)

@@ -155,3 +155,36 @@ def test_full_size_properties_1080p_r100(engine):
     assert np.array_equal(d["match_idx"].reshape(-1), rows)
     assert d["match_cos"].min() > 0.999
     engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_other_config_shapes_4k_720p_and_million_gallery(engine):
+    """Shapes of BASELINE configs 4 and 5 through the same path: one 3840x2160 frame (340,320 anchors,
+    canvas 2176 rows), a mixed batch of 1280x720 frames, and a 1M-identity gallery (1.02 GB fp16)."""
+    from frp_amd import native
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(31)
+    K = 6
+    f4k = rng.integers(0, 256, size=(1, 2160, 3840, 3), dtype=np.uint8)
+    a = engine.detect(f4k, max_faces=K, flags=native.FLAG_FORCED_K)
+    heads = engine.head_maps()
+    assert [h.shape[1:3] for h in heads] == [(272, 480), (136, 240), (68, 120)]
+    ob, ok, osc, oa = onet.decode_nms([h[0] for h in heads], 0.0, 2.0, K)
+    assert np.array_equal(a["anchor_idx"][0], oa) and np.array_equal(a["boxes"][0], ob)      # exact at 4K too
+    f720 = rng.integers(0, 256, size=(5, 720, 1280, 3), dtype=np.uint8)
+    o = engine.process_frames(f720, max_faces=K, flags=native.FLAG_FORCED_K | native.FLAG_NO_MATCH)
+    assert np.all(o["counts"] == K) and np.abs(np.linalg.norm(o["emb"], axis=-1) - 1).max() < 1e-4
+    single = engine.process_frames(f720[3:4], max_faces=K, flags=native.FLAG_FORCED_K | native.FLAG_NO_MATCH)
+    assert np.array_equal(single["emb"][0], o["emb"][3])                  # batch position does not matter
+    # 1M gallery: planted rows found, cosine within 1e-3 of float64
+    N = 1_000_000
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    engine.gallery_set(G)
+    rows = rng.choice(N, size=9, replace=False)
+    Q = G[rows] + 0.02 * rng.standard_normal((9, 512)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    idx, cos = engine.match(Q)
+    assert np.array_equal(idx, rows)
+    assert np.abs(cos - (Q.astype(np.float64) * G[rows].astype(np.float64)).sum(1)).max() < 1e-3
+    engine.gallery_set(np.zeros((0, 512), np.float32))

@@ -252,3 +252,18 @@ def test_blob_layout_and_buffer_liveness():
         holder[out_buf] = l.dst
         holder.setdefault(in_buf, l.src)
         assert op[10] % 16 == 0 and op[11] % 16 == 0 and 0 <= out_buf < n_det_bufs
+
+
+def test_arcface_checkpoint_loader_roundtrip(tmp_path):
+    """a checkpoint in the public arcface_torch naming loads into the raw dict pack_blob consumes"""
+    raw = weights.make_synthetic_raw(11, (1, 1, 1, 1), (1, 2, 1, 1), want_det=False)
+    sd = {"module." + k[4:]: torch.from_numpy(v) for k, v in raw.items()}
+    sd["module.bn1.num_batches_tracked"] = torch.tensor(5)
+    path = str(tmp_path / "backbone.pth")
+    torch.save({"state_dict": sd}, path)
+    got = weights.load_arcface_state_dict(path)
+    assert set(got) == set(raw) and all(np.array_equal(got[k], raw[k]) for k in raw)
+    assert weights.emb_blocks_of(got) == (1, 2, 1, 1)
+    det = weights.make_synthetic_raw(11, (1, 1, 1, 1), (1, 2, 1, 1), want_emb=False)
+    blob = weights.pack_blob({**det, **got}, (1, 1, 1, 1), weights.emb_blocks_of(got))
+    assert blob[:8] == b"FRPBLOB1"
