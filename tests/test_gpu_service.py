@@ -81,3 +81,34 @@ def test_encode_face_and_lower_api(engine, tmp_path, monkeypatch):
     rb = fs.batch_encode_faces([p, str(tmp_path / "missing.png")])
     assert rb[0]["success"] and rb[0]["image_path"] == p and not rb[1]["success"]
     fs.ENCODINGS.clear()
+
+
+def test_concurrent_callers_share_one_handle(engine):
+    """The reference calls the service from ThreadPoolExecutor(4) workers (routes/camera.py:30,277-279);
+    one handle serialises them internally: results equal the serial ones."""
+    import threading
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(8)
+    G = rng.standard_normal((2000, 512)).astype(np.float32)
+    engine.gallery_set(G)
+    frames = [rng.integers(0, 256, size=(1 + i % 2, 96 + 32 * (i % 3), 128, 3), dtype=np.uint8) for i in range(8)]
+    serial = [engine.process_frames(f, max_faces=3, flags=1) for f in frames]
+    out = [None] * len(frames)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = engine.process_frames(frames[i], max_faces=3, flags=1)
+        except Exception as e:   # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(frames))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for a, b in zip(serial, out):
+        for k in ("boxes", "emb", "match_idx", "match_cos"):
+            assert np.array_equal(a[k], b[k]), k
+    engine.gallery_set(np.zeros((0, 512), np.float32))
