@@ -237,6 +237,47 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
     if (tid == 0) p.counts[b] = kept;
 }
 
+// Bilinear down/up-scale of u8 frames for the multi-scale pyramid (BASELINE config 4).  Pixel centres:
+// src = (dst + 0.5) * (S / D) - 0.5, clamped to the image; fp32 lerp in x then y with one rounding per
+// operation (this file is built with -ffp-contract=off), result floor(v + 0.5) -> u8.
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ src, int B, int H, int W,
+                                                        uint8_t* __restrict__ dst, int Hs, int Ws, float ry, float rx) {
+    const long total = (long)B * Hs * Ws;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Ws);
+        const long r = i / Ws;
+        const int y = (int)(r % Hs);
+        const int b = (int)(r / Hs);
+        float sy = ((float)y + 0.5f) * ry - 0.5f, sx = ((float)x + 0.5f) * rx - 0.5f;
+        sy = fminf(fmaxf(sy, 0.0f), (float)(H - 1));
+        sx = fminf(fmaxf(sx, 0.0f), (float)(W - 1));
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+        const float fy = sy - (float)y0, fx = sx - (float)x0;
+        const uint8_t* p00 = src + (((long)b * H + y0) * W + x0) * 3;
+        const uint8_t* p01 = src + (((long)b * H + y0) * W + x1) * 3;
+        const uint8_t* p10 = src + (((long)b * H + y1) * W + x0) * 3;
+        const uint8_t* p11 = src + (((long)b * H + y1) * W + x1) * 3;
+        uint8_t* o = dst + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = (float)p00[c] * (1.0f - fx) + (float)p01[c] * fx;
+            const float bot = (float)p10[c] * (1.0f - fx) + (float)p11[c] * fx;
+            const float v = top * (1.0f - fy) + bot * fy;
+            o[c] = (uint8_t)fminf(fmaxf(floorf(v + 0.5f), 0.0f), 255.0f);
+        }
+    }
+}
+
+hipError_t launch_resize_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int Hs, int Ws, hipStream_t stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0) return hipErrorInvalidValue;
+    const long total = (long)B * Hs * Ws;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid), dim3(256), 0, stream, src, B, H, W, dst, Hs, Ws,
+                       (float)H / (float)Hs, (float)W / (float)Ws);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.max_faces <= 0 || p.max_faces > FRP_MAX_FACES_CAP) return hipErrorInvalidValue;
     long A = 0;

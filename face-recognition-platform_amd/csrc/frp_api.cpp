@@ -56,6 +56,10 @@ struct frp_handle {
     // resident frames (tightly packed u8 [B,H,W,3])
     DevBuf frames;
     int rB = 0, rH = 0, rW = 0;
+    // detector source: the resident frames, or a resized copy of them (pyramid scales)
+    DevBuf scaled;
+    int dH = 0, dW = 0;              // dims of the detector source
+    bool det_scaled = false;
     int canvas_h = 0, canvas_w = 0;
     // per-call results (device)
     DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws, dense_logits;
@@ -273,8 +277,27 @@ int upload_frames(frp_handle* h, const uint8_t* bgr, int B, int H, int W, int64_
                                hipMemcpyHostToDevice, h->stream));
     rec(h, EV_H2D);
     h->rB = B; h->rH = H; h->rW = W;
+    h->dH = H; h->dW = W; h->det_scaled = false;
     h->canvas_h = round_up(H, 32);
     h->canvas_w = round_up(W, 32);
+    return FRP_OK;
+}
+
+// choose the detector source: the resident frames (Hs,Ws == frame size) or a bilinear resize of them
+int select_det_source(frp_handle* h, int Hs, int Ws) {
+    if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
+    if (Hs <= 0 || Ws <= 0 || Hs > 16384 || Ws > 16384) return fail(h, FRP_ERR_INVALID, "bad detector size");
+    if (Hs == h->rH && Ws == h->rW) {
+        h->det_scaled = false;
+    } else {
+        FRPCHK(ensure(h, h->scaled, (size_t)h->rB * Hs * Ws * 3));
+        hipError_t e = launch_resize_u8((const uint8_t*)h->frames.p, h->rB, h->rH, h->rW, (uint8_t*)h->scaled.p, Hs, Ws, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("resize: ") + hipGetErrorString(e));
+        h->det_scaled = true;
+    }
+    h->dH = Hs; h->dW = Ws;
+    h->canvas_h = round_up(Hs, 32);
+    h->canvas_w = round_up(Ws, 32);
     return FRP_OK;
 }
 
@@ -303,14 +326,15 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
     FRPCHK(ensure_results(h, B, K));
     hipError_t e = hipSuccess;
     StemParams sp{};
+    const uint8_t* dsrc = h->det_scaled ? (const uint8_t*)h->scaled.p : (const uint8_t*)h->frames.p;
     if (fused) {
-        sp.frames = (const uint8_t*)h->frames.p;
-        sp.B = B; sp.H = h->rH; sp.W = h->rW;
-        sp.row_stride = (long)h->rW * 3; sp.frame_stride = (long)h->rH * h->rW * 3;
+        sp.frames = dsrc;
+        sp.B = B; sp.H = h->dH; sp.W = h->dW;
+        sp.row_stride = (long)h->dW * 3; sp.frame_stride = (long)h->dH * h->dW * 3;
         sp.Hc = Hc; sp.Wc = Wc; sp.Ho = Hc / 2; sp.Wo = Wc / 2;
         sp.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
     } else {
-        e = launch_preprocess((const uint8_t*)h->frames.p, B, h->rH, h->rW, (long)h->rW * 3, (long)h->rH * h->rW * 3,
+        e = launch_preprocess(dsrc, B, h->dH, h->dW, (long)h->dW * 3, (long)h->dH * h->dW * 3,
                               (_Float16*)h->det.bufs[h->det.in_buf].p, Hc, Wc, (flags & FRP_FLAG_RGB) ? 1 : 0, h->stream);
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
     }
@@ -389,13 +413,13 @@ int run_match(frp_handle* h, int n, float* all_scores_dev) {
     return FRP_OK;
 }
 
-int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
-    FRPCHK(run_detect(h, K, det_thresh, nms_iou, flags));
+// align + embed + match for the faces listed in h->kps / h->counts / h->face_slot (device), always from
+// the full-resolution resident frames.  n_known >= 0: face count known on the host.
+int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
     const int B = h->rB;
     int n;
-    const long A = (long)h->det.dims[h->hdr.det_head_buf[0]].h * h->det.dims[h->hdr.det_head_buf[0]].w * 2;
-    if ((flags & FRP_FLAG_FORCED_K) && A >= K) {
-        n = B * K;   // known without a device round trip
+    if (n_known >= 0) {
+        n = n_known;
     } else {
         HIPCHK(h, hipMemcpyAsync(h->h_nfaces, h->nfaces.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -433,6 +457,13 @@ int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t
     h->ctr.frames += B;
     h->ctr.faces += n;
     return FRP_OK;
+}
+
+int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
+    if (h->det_scaled) FRPCHK(select_det_source(h, h->rH, h->rW));     // the fused path always detects at full size
+    FRPCHK(run_detect(h, K, det_thresh, nms_iou, flags));
+    const long A = (long)h->det.dims[h->hdr.det_head_buf[0]].h * h->det.dims[h->hdr.det_head_buf[0]].w * 2;
+    return run_faces(h, K, ((flags & FRP_FLAG_FORCED_K) && A >= K) ? h->rB * K : -1, flags);   // forced-K: count known
 }
 
 void accumulate_events(frp_handle* h, bool with_h2d) {
@@ -569,7 +600,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
-                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->gallery};
+                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
@@ -757,6 +788,66 @@ int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->last_nfaces = 0;
     return FRP_OK;
+}
+
+int frp_detect_resident(frp_handle* h, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
+                        uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    FRPCHK(select_det_source(h, det_h, det_w));
+    FRPCHK(run_detect(h, max_faces, det_thresh, nms_iou, flags));
+    const int B = h->rB;
+    const size_t s = (size_t)B * max_faces;
+    if (boxes) HIPCHK(h, hipMemcpyAsync(boxes, h->boxes.p, s * 16, hipMemcpyDeviceToHost, h->stream));
+    if (kps) HIPCHK(h, hipMemcpyAsync(kps, h->kps.p, s * 40, hipMemcpyDeviceToHost, h->stream));
+    if (scores) HIPCHK(h, hipMemcpyAsync(scores, h->scores.p, s * 4, hipMemcpyDeviceToHost, h->stream));
+    if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (anchor_idx) HIPCHK(h, hipMemcpyAsync(anchor_idx, h->anchor.p, s * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->last_nfaces = 0;
+    return FRP_OK;
+}
+
+int frp_get_det_source(frp_handle* h, uint8_t* out, int64_t out_bytes, int32_t* hs, int32_t* ws) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames");
+    if (hs) *hs = h->dH;
+    if (ws) *ws = h->dW;
+    const int64_t need = (int64_t)h->rB * h->dH * h->dW * 3;
+    if (!out) return FRP_OK;
+    if (out_bytes < need) return fail(h, FRP_ERR_INVALID, "buffer too small");
+    HIPCHK(h, hipMemcpyAsync(out, h->det_scaled ? h->scaled.p : h->frames.p, (size_t)need, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_finish_faces(frp_handle* h, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
+                     int32_t max_faces, uint32_t flags, float* emb, int32_t* match_idx, float* match_cos) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+    if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
+    if (!kps || !counts || max_faces <= 0 || max_faces > FRP_MAX_FACES_CAP) return fail(h, FRP_ERR_INVALID, "bad face list");
+    const int B = h->rB, K = max_faces;
+    int n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (counts[b] < 0 || counts[b] > K) return fail(h, FRP_ERR_INVALID, "face count out of range");
+        n += counts[b];
+    }
+    FRPCHK(ensure_results(h, B, K));
+    const size_t s = (size_t)B * K;
+    HIPCHK(h, hipMemcpyAsync(h->kps.p, kps, s * 40, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->counts.p, counts, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (boxes) HIPCHK(h, hipMemcpyAsync(h->boxes.p, boxes, s * 16, hipMemcpyHostToDevice, h->stream));
+    if (scores) HIPCHK(h, hipMemcpyAsync(h->scores.p, scores, s * 4, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_compact_faces((const int32_t*)h->counts.p, B, K, (int32_t*)h->face_slot.p, (int32_t*)h->nfaces.p, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("compact_faces: ") + hipGetErrorString(e));
+    h->last_B = B;
+    h->last_K = K;
+    rec(h, EV_DEC);
+    FRPCHK(run_faces(h, K, n, flags));
+    return fetch_results(h, nullptr, nullptr, nullptr, nullptr, emb, match_idx, match_cos);
 }
 
 int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl) {

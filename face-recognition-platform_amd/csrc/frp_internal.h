@@ -70,6 +70,9 @@ struct DecodeParams {
 };
 hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream);
 
+// u8 bilinear resize for the detection pyramid (frames [B,H,W,3] tightly packed)
+hipError_t launch_resize_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int Hs, int Ws, hipStream_t stream);
+
 // K4: 5-point similarity + bilinear warp to 112x112 -> normalised fp16 NHWC8 chips
 struct AlignParams {
     const uint8_t* frames;  // [B,H,W,3] u8 BGR

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_update_row", "frp_gallery_remove_row",
     "frp_gallery_size", "frp_gallery_get",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
-    "frp_detect", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
+    "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
     "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_get_counters", "frp_reset_counters",
 ]
 
@@ -84,6 +84,9 @@ def load_library() -> C.CDLL:
     lib.frp_fetch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.frp_synchronize.argtypes = [vp]
     lib.frp_detect.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp]
+    lib.frp_detect_resident.argtypes = [vp, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
+    lib.frp_get_det_source.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.frp_finish_faces.argtypes = [vp, vp, vp, vp, vp, i32, u32, vp, vp, vp]
     lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.frp_decode_heads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_align.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
@@ -227,6 +230,53 @@ class Engine:
         o["anchor_idx"] = anchor
         self._det_batch = B
         return o
+
+    def detect_resident(self, det_hw, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
+        """detect on the resident frames resized to det_hw (pyramid scale); coordinates of the resized image"""
+        B = self._resident[0]
+        o = self._alloc(B, max_faces)
+        anchor = np.full((B, max_faces), -1, np.int32)
+        self._chk(self._lib.frp_detect_resident(self._h, det_hw[0], det_hw[1], max_faces, det_thresh, nms_iou, flags,
+                                                _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]), _ptr(anchor)))
+        o["anchor_idx"] = anchor
+        self._det_batch = B
+        return {k: o[k] for k in ("boxes", "kps", "scores", "counts", "anchor_idx")}
+
+    def det_source(self) -> np.ndarray:
+        """the u8 frames the detector last read (resident frames or their pyramid resize)"""
+        hs, ws = C.c_int32(), C.c_int32()
+        self._chk(self._lib.frp_get_det_source(self._h, None, 0, C.byref(hs), C.byref(ws)))
+        out = np.empty((self._resident[0], hs.value, ws.value, 3), np.uint8)
+        self._chk(self._lib.frp_get_det_source(self._h, _ptr(out), out.nbytes, C.byref(hs), C.byref(ws)))
+        return out
+
+    def finish_faces(self, boxes, kps, scores, counts, max_faces, flags=0):
+        """align (from the full-resolution resident frames) + embed + match for caller-supplied landmarks"""
+        B = self._resident[0]
+        boxes = np.ascontiguousarray(boxes, np.float32).reshape(B, max_faces, 4)
+        kps = np.ascontiguousarray(kps, np.float32).reshape(B, max_faces, 5, 2)
+        scores = np.ascontiguousarray(scores, np.float32).reshape(B, max_faces)
+        counts = np.ascontiguousarray(counts, np.int32).reshape(B)
+        o = self._alloc(B, max_faces)
+        self._chk(self._lib.frp_finish_faces(self._h, _ptr(boxes), _ptr(kps), _ptr(scores), _ptr(counts), max_faces, flags,
+                                             _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
+        o.update(boxes=boxes, kps=kps, scores=scores, counts=counts)
+        return o
+
+    def process_frames_pyramid(self, frames, scales=(1.0, 0.5, 0.25), max_faces=10, det_thresh=0.5, nms_iou=0.4,
+                               per_scale=64, flags=0):
+        """BASELINE config 4: detect at several scales of every frame, merge + NMS across scales
+        (pyramid.merge_scales), then align / embed / match from the full-resolution frames."""
+        from . import pyramid
+        frames, B, H, W, _ = self._frames(frames)
+        self.upload_frames(frames)
+        per = []
+        for s in scales:
+            hw = pyramid.scaled_size(H, W, s)
+            per.append((hw, self.detect_resident(hw, max_faces=per_scale, det_thresh=det_thresh, nms_iou=nms_iou,
+                                                 flags=flags & ~FLAG_FORCED_K)))
+        boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), max_faces, nms_iou)
+        return self.finish_faces(boxes, kps, scores, counts, max_faces, flags & (FLAG_RGB | FLAG_NO_MATCH))
 
     def head_maps(self):
         """fp16 head maps [B,H_l,W_l,32] of the last detect/process call, strides 8/16/32."""

@@ -139,6 +139,18 @@ int frp_synchronize(frp_handle* h);
 int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,
                int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags,
                float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx);
+/* Multi-scale pyramid building blocks (BASELINE config 4: "RetinaFace multi-scale pyramid"):
+ * detect on the RESIDENT frames bilinearly resized to det_h x det_w (== frame size: no resize); boxes and
+ * landmarks come back in the coordinates of the resized image.  The caller merges the scales
+ * (pyramid.merge_scales) and hands the merged landmarks to frp_finish_faces, which aligns from the
+ * full-resolution resident frames, embeds and matches.  counts[b] <= max_faces faces per frame. */
+int frp_detect_resident(frp_handle* h, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
+                        uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx);
+/* the u8 frames the detector last read (the resident frames or their resize), [B, hs, ws, 3] (parity tests) */
+int frp_get_det_source(frp_handle* h, uint8_t* out, int64_t out_bytes, int32_t* hs, int32_t* ws);
+int frp_finish_faces(frp_handle* h, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
+                     int32_t max_faces, uint32_t flags, float* emb, int32_t* match_idx, float* match_cos);
+
 /* raw detector head maps of the last detect/process call, per stride level 0..2:
  * [B, H/stride, W/stride, 32] fp16 (parity tests) */
 int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl);

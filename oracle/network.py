@@ -288,6 +288,69 @@ def cos_to_distance(cos):
     return np.sqrt(np.maximum(0.0, 2.0 - 2.0 * np.asarray(cos, dtype=np.float64)))
 
 
+# ----------------------------------------------------------------------------- multi-scale pyramid
+def resize_bilinear_u8(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """[H,W,C] u8 -> [Hs,Ws,C] u8.  Pixel centres src = (dst+0.5)*(S/D) - 0.5 clamped to the image,
+    fp32 lerp in x then y (one rounding per operation), floor(v+0.5).  (cv2.resize INTER_LINEAR
+    geometry; cv2's own fixed-point rounding is not reproduced -- the oracle defines the rule.)"""
+    f32 = np.float32
+    H, W = img.shape[:2]
+    Hs, Ws = out_hw
+    ry, rx = f32(H) / f32(Hs), f32(W) / f32(Ws)
+    sy = np.clip(((np.arange(Hs, dtype=f32) + f32(0.5)) * ry - f32(0.5)).astype(f32), f32(0), f32(H - 1))
+    sx = np.clip(((np.arange(Ws, dtype=f32) + f32(0.5)) * rx - f32(0.5)).astype(f32), f32(0), f32(W - 1))
+    y0, x0 = sy.astype(np.int64), sx.astype(np.int64)
+    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+    fy, fx = (sy - y0.astype(f32)).astype(f32)[:, None, None], (sx - x0.astype(f32)).astype(f32)[None, :, None]
+    im = img.astype(f32)
+    top = ((im[y0][:, x0] * (f32(1) - fx)).astype(f32) + (im[y0][:, x1] * fx).astype(f32)).astype(f32)
+    bot = ((im[y1][:, x0] * (f32(1) - fx)).astype(f32) + (im[y1][:, x1] * fx).astype(f32)).astype(f32)
+    v = ((top * (f32(1) - fy)).astype(f32) + (bot * fy).astype(f32)).astype(f32)
+    return np.clip(np.floor(v + f32(0.5)), 0, 255).astype(np.uint8)
+
+
+def detect_pyramid(raw, frame_bgr: np.ndarray, scales=(1.0, 0.5, 0.25), score_thresh=0.5, nms_iou=0.4, max_faces=10,
+                   per_scale=64, head_maps_per_scale=None):
+    """One frame.  Per scale: resize, detector, decode + NMS keeping `per_scale` boxes; map back to frame
+    pixels (x * W/Ws, y * H/Hs); concatenate in scale order; stable sort by score desc; greedy +1-area NMS;
+    first max_faces.  `head_maps_per_scale` (optional) substitutes the detector outputs (the GPU's own head
+    maps) so that the merge logic can be checked bit for bit.  -> boxes, kps, scores"""
+    f32 = np.float32
+    H, W = frame_bgr.shape[:2]
+    allb, allk, alls = [], [], []
+    for si, s in enumerate(scales):
+        Hs, Ws = max(1, int(round(H * s))), max(1, int(round(W * s)))
+        if head_maps_per_scale is not None:
+            maps = head_maps_per_scale[si]
+        else:
+            img = frame_bgr if (Hs, Ws) == (H, W) else resize_bilinear_u8(frame_bgr, (Hs, Ws))
+            canvas = ((Hs + 31) // 32 * 32, (Ws + 31) // 32 * 32)
+            maps = [m[0] for m in det_forward(raw, det_blob(img[None], canvas))]
+        b, k, sc, _ = decode_nms(maps, score_thresh, nms_iou, per_scale)
+        ry, rx = f32(H) / f32(Hs), f32(W) / f32(Ws)
+        allb.append((b * np.array([rx, ry, rx, ry], f32)).astype(f32))
+        allk.append((k * np.array([rx, ry], f32)).astype(f32))
+        alls.append(sc.astype(f32))
+    b, k, sc = np.concatenate(allb), np.concatenate(allk), np.concatenate(alls)
+    order = np.argsort(-sc, kind="stable")
+    b, k, sc = b[order], k[order], sc[order]
+    keep, supp = [], np.zeros(len(b), bool)
+    area = ((b[:, 2] - b[:, 0] + f32(1)) * (b[:, 3] - b[:, 1] + f32(1))).astype(f32)
+    for i in range(len(b)):
+        if supp[i]:
+            continue
+        keep.append(i)
+        if len(keep) >= max_faces:
+            break
+        for j in range(i + 1, len(b)):
+            w = max(f32(0), f32(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0]) + f32(1)))
+            h = max(f32(0), f32(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1]) + f32(1)))
+            inter = f32(w * h)
+            if f32(inter / f32(f32(area[i] + area[j]) - inter)) > f32(nms_iou):
+                supp[j] = True
+    return b[keep], k[keep], sc[keep]
+
+
 # ----------------------------------------------------------------------------- end to end
 def process_frames(raw, frames_bgr: np.ndarray, gallery: Optional[np.ndarray], canvas_hw=None,
                    score_thresh=0.5, nms_iou=0.4, max_faces=10):

@@ -188,3 +188,66 @@ def test_other_config_shapes_4k_720p_and_million_gallery(engine):
     assert np.array_equal(idx, rows)
     assert np.abs(cos - (Q.astype(np.float64) * G[rows].astype(np.float64)).sum(1)).max() < 1e-3
     engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_resize_and_pyramid_merge(engine):
+    """Config-4 pyramid: the device resize is bit-exact vs the oracle's rule, per-scale detections equal
+    the oracle decode of the GPU's own head maps, and the cross-scale merge + NMS equals the oracle's
+    independent (scalar-loop) restatement; faces are then embedded from the full-resolution frame."""
+    from frp_amd import native, pyramid
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(99)
+    H, W = 360, 500
+    frames = _frames(rng, 2, H, W)
+    scales = (1.0, 0.5, 0.25)
+    engine.upload_frames(frames)
+    thr = 0.30
+    per, head_sets = [], []
+    for s in scales:
+        hw = pyramid.scaled_size(H, W, s)
+        d = engine.detect_resident(hw, max_faces=64, det_thresh=thr, nms_iou=0.4)
+        heads = engine.head_maps()
+        head_sets.append(heads)
+        per.append((hw, d))
+        # the resized image the detector saw: check through the oracle on frame 0 (fp16 heads within tolerance)
+        if s != 1.0:
+            img = onet.resize_bilinear_u8(frames[0], hw)
+            ref = onet.det_forward(raw, onet.det_blob(img[None], ((hw[0] + 31) // 32 * 32, (hw[1] + 31) // 32 * 32)))
+            for g, r in zip(heads, ref):
+                assert np.abs(g[0, ..., :30].astype(np.float32) - r[0]).max() < 2e-2 * max(1.0, float(np.abs(r).max()))
+    boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), 8, 0.4)
+    for b in range(2):
+        ob, ok, osc = onet.detect_pyramid(raw, frames[b], scales, thr, 0.4, 8, 64,
+                                          head_maps_per_scale=[[h[b] for h in hs] for hs in head_sets])
+        n = len(ob)
+        assert counts[b] == n and n >= 2
+        assert np.array_equal(boxes[b, :n], ob) and np.array_equal(kps[b, :n], ok)
+        assert np.abs(scores[b, :n] - osc).max() < 1e-6
+    # whole call: same detections, embeddings from the full-resolution frame
+    G = rng.standard_normal((64, 512)).astype(np.float32)
+    engine.gallery_set(G)
+    out = engine.process_frames_pyramid(frames, scales, max_faces=8, det_thresh=thr, nms_iou=0.4)
+    assert np.array_equal(out["counts"], counts) and np.array_equal(out["boxes"], boxes)
+    for b in range(2):
+        n = counts[b]
+        e = engine.embed_faces(frames[b], kps[b, :n])
+        assert np.abs(e - out["emb"][b, :n]).max() < 1e-6
+        assert np.all(out["match_idx"][b, :n] >= 0) and np.all(out["match_idx"][b, n:] == -1)
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_resize_bit_exact(engine):
+    """device bilinear resize == the oracle's rule, bit for bit (down- and up-scaling, odd sizes)"""
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(2, 128, 192, 3), dtype=np.uint8)
+    engine.upload_frames(img)
+    for hw in [(64, 96), (37, 51), (128, 192), (200, 300), (32, 33)]:
+        engine.detect_resident(hw, max_faces=4, flags=1)
+        got = engine.det_source()
+        assert got.shape == (2, hw[0], hw[1], 3)
+        for b in range(2):
+            ref = img[b] if hw == (128, 192) else onet.resize_bilinear_u8(img[b], hw)
+            assert np.array_equal(got[b], ref), hw
