@@ -33,74 +33,9 @@
 #include <stdint.h>
 #include <type_traits>
 #include "frp_internal.h"
+#include "conv_common.h"
 
 namespace frp {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-#define CONV_NS 3            // LDS ring stages
-#define CONV_OOB 0x80000000u // buffer offset beyond any tensor (< 2 GiB each): reads as zero
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// one LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets to lds_base + lane*16.
-// (kept in a __device__ function: the builtin does not exist for the host pass)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, unsigned voffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
-}
-
-// (device-only constructs must live in __device__ functions: written directly in the __global__
-// template body they make the HOST pass drop the kernel stub without a diagnostic)
-__device__ __forceinline__ void keep_alive(floatx16 v) { asm volatile("" ::"v"(v)); }
-// Half-wave exchange: lane<32 ends up with this pixel's couts [lo | upper lane's lo] (16 contiguous
-// bytes), lane>=32 with [lower lane's hi | hi]: two 8-byte stores per lane become one 16-byte store
-// (the epilogue store tail is issue-bound, not bandwidth-bound).
-__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
-}
-// diagnostic stamps (conv_bench only, p.stamps != null): 100 MHz wall clock per workgroup phase,
-// written to a buffer nothing else reads
-__device__ __forceinline__ void stamp(unsigned long long* buf, int slot) {
-    if (buf && threadIdx.x == 0) buf[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-}
-// keeps hipcc from hoisting the loads of every epilogue slice above the first one (which
-// would need several hundred live registers)
-__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-
-static int device_cu_count(int dev) {
-    static int n_cu[64] = {};
-    if (!n_cu[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n_cu[dev];
-}
-
-// q = m / d, r = m % d for 0 <= m < 2^24 via a float reciprocal and one correction step
-// (an integer division costs ~40 instructions; the prologue needs two per pixel row)
-__device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
-    q = (int)((float)m * inv_d);
-    r = m - q * d;
-    if (r < 0) { --q; r += d; }
-    if (r >= d) { ++q; r -= d; }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "add the literal");
-}
 
 template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(ConvParams p) {
@@ -148,6 +83,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     unsigned woff[WI];     // byte offset of (cout row, k=chunk); rows >= Cout are out of range -> zeros
     int kh = 0, kw = 0, cb = 0;               // aligned path: uniform (tap, 64-channel block) walk
     const int cpt = p.Cin >> 6;
+    const bool tap_major = p.dbg & 8;         // A/B: the old (tap, channel block) K order
     int it = t0, iks = 0, ibuf = 0;           // issue cursor: tile, k-step, ring slot
     int iks_base = 0;                         // first k-step of the issue cursor's slice
     auto setup_issue_tile = [&](int vtile) {
@@ -185,11 +121,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             const int co = c0i + (i * NW + wave) * 8 + lrow;
             woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
         }
-        if constexpr (!SMALL) {                  // start of the slice in the (tap, channel block) walk
-            const int tap = iks_base / cpt;
-            cb = iks_base - tap * cpt;
-            kh = tap / p.KS;
-            kw = tap - kh * p.KS;
+        if constexpr (!SMALL) {                  // start of the slice in the (channel block, tap) walk
+            const int taps = p.KS * p.KS;
+            if (tap_major) {
+                const int tap = iks_base / cpt;
+                cb = iks_base - tap * cpt;
+                kh = tap / p.KS;
+                kw = tap - kh * p.KS;
+            } else {
+                cb = iks_base / taps;
+                const int tap = iks_base - cb * taps;
+                kh = tap / p.KS;
+                kw = tap - kh * p.KS;
+            }
         }
     };
 
@@ -205,7 +149,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
         if constexpr (!SMALL) {
             st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
             st_bit = 1u << (kh * 3 + kw);
-            if (++cb == cpt) { cb = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+            st_wadd = (unsigned)(((kh * p.KS + kw) * cpt + cb) << 7);
+            if (tap_major) {
+                if (++cb == cpt) { cb = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+            } else {
+                if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cb; } }
+            }
         } else {
             const int kg = (ks << 6) + lchunk * 8;
             const int tap = kg >> p.cin_shift;
@@ -216,8 +165,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             st_bit = kg < p.Ktot ? 1u << (tkh * 3 + tkw) : 0u;
             // weights: a k chunk beyond Ktot (small-Cin tail) would read the NEXT row, so guard it
             st_kin = kg < p.Ktot;
+            st_wadd = (unsigned)(ks << 7);
         }
-        st_wadd = (unsigned)(ks << 7);
     };
     auto x_off = [&](int i) -> unsigned { return (tapmask[i] & st_bit) ? (unsigned)(xoff[i] + st_tapoff) : CONV_OOB; };
     auto w_off = [&](int i) -> unsigned { return (st_kin && woff[i] != CONV_OOB) ? woff[i] + st_wadd : CONV_OOB; };
@@ -583,6 +532,8 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if ((p.flags & FRP_FLAG_RES_UP2) && (!p.res || p.Hr * 2 != p.Ho || p.Wr * 2 != p.Wo)) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.bias || !p.out) return hipErrorInvalidValue;
     if (p.act == FRP_ACT_PRELU && !p.slope) return hipErrorInvalidValue;
+    // 3x3 stride-1 layers with whole 64-channel blocks: row-patch kernel (a third of the LDS-DMA traffic)
+    if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
     // Tile selection (measured on MI355X, tools/conv_bench.py):
     //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one
     //               workgroup per CU).  Two independent 4-wave 128x128 groups per CU (2-slot
@@ -597,6 +548,8 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     } else {
         // narrow layers: 256 x 64, 8 waves (32x64 each), 3-slot ring (a 512 x 64 tile with 64x64
         // per wave measured 10 % slower: these 9-step layers are bound by per-tile overheads)
+        if (force == 2)
+            return small ? launch_cfg<128, 64, 4, 1, 3, 4, true>(p, stream) : launch_cfg<128, 64, 4, 1, 3, 4, false>(p, stream);
         return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
     }
 }

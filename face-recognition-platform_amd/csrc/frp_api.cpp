@@ -1057,6 +1057,7 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.out = dout.p;
             p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
+            p.dbg = (flags >> 8) & 0xff;      // kernel A/B switches (tests: 1 = generic kernel instead of the row-patch one)
             p.Hr = res_h; p.Wr = res_w;
             e = launch_conv(p, h->stream);
         }

@@ -29,13 +29,18 @@ struct ConvParams {
     int Hr, Wr;             // residual spatial dims (RES_UP2)
     int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
-    int dbg;                // tuning ablations (conv_bench only): 1 = no DMA in the loop, 2 = no MFMA
+    int dbg;                // A/B switches (conv_bench only): 1 = generic kernel for row-patch shapes, 8 = tap-major k order,
+                            // 16 / 32 = alternative tile configurations
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
     unsigned x_bytes, w_bytes;   // buffer-descriptor sizes (each < 2 GiB)
 };
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
+// row-patch variant for 3x3 stride-1 layers with Cin % 64 == 0 (conv3x3_rows.hip); launch_conv()
+// routes eligible shapes to it.  `p` must carry launch_conv()'s derived fields.
+bool conv3x3_rows_eligible(const ConvParams& p);
+hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);
 
 // K1: u8 BGR frames -> normalised fp16 NHWC8 canvas (top-left letterbox, zero u8 pad)
 hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,

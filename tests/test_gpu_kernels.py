@@ -51,6 +51,14 @@ CONV_CASES = [
     (1, 5, 7, 64, 64, 3, 1, 1, True, 0),        # ragged: M=35 << tile
     (5, 28, 28, 128, 128, 3, 1, 2, True, 1),    # multi-tile, all epilogue features
     (1, 40, 24, 64, 64, 3, 2, 1, False, 0),
+    # row-patch kernel (3x3 s1, Cin % 64 == 0): image width around / beyond the 256-pixel tile, many images
+    # per tile, ragged last tile, two cout tiles, Cout not a multiple of the tile
+    (1, 3, 300, 64, 64, 3, 1, 1, False, 0),     # W > tile: the three kh patches do not overlap
+    (40, 7, 7, 128, 128, 3, 1, 2, True, 1),     # 5 images per tile, border bias + residual + PReLU
+    (3, 30, 33, 192, 256, 3, 1, 1, True, 0),    # 3 channel blocks, 2 cout tiles, ragged M
+    (2, 19, 21, 64, 96, 3, 1, 0, False, 0),     # Cout = 96: ragged cout tile
+    (1, 1, 1, 64, 64, 3, 1, 0, False, 0),       # single pixel: every tap but the centre is padding
+    (2, 2, 2, 128, 32, 3, 1, 1, False, 0),
 ]
 
 
@@ -74,6 +82,21 @@ def test_conv_parity(engine, case):
     tol = 2e-3 * max(1.0, float(np.abs(ref).max())) if not (flags & 2) else 1e-4 * max(1.0, float(np.abs(ref).max()))
     err = np.abs(out.astype(np.float32) - ref).max()
     assert err <= tol, f"max err {err} > {tol}"
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and c[3] % 64 == 0])
+def test_conv_row_patch_kernel_equals_generic_kernel(engine, case):
+    """conv3x3_rows.hip and conv_mfma.hip accumulate in the same k order -> identical bits."""
+    N, H, W, Cin, Cout, k, stride, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float16)
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
+    a = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags)
+    b = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | (1 << 8))
+    assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
 
 
 def test_conv_rejects_unsupported_shape(engine):

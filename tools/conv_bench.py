@@ -28,19 +28,27 @@ SHAPES = [
 
 
 def main():
+    """conv_bench.py [iters] [dbgA] [dbgB]: with dbgB given the two variants alternate in this one
+    process (3 rounds, best of each) so that box-to-box and run-to-run drift cancels."""
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 16: force the large tile, 32: force the medium tile
+    dbgs = [int(a) for a in sys.argv[2:4]] or [0]
     eng = native.Engine(0)
-    tot = 0.0
+    tot = [0.0] * len(dbgs)
     for (name, N, H, W, Cin, Cout, k, s, act, flags, res, cnt) in SHAPES:
-        ms = eng.conv_bench(N, H, W, Cin, Cout, k, s, act, flags | (dbg << 8), res, iters)
+        best = [1e30] * len(dbgs)
+        for _ in range(3 if len(dbgs) > 1 else 1):
+            for v, dbg in enumerate(dbgs):
+                best[v] = min(best[v], eng.conv_bench(N, H, W, Cin, Cout, k, s, act, flags | (dbg << 8), res, iters))
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
         cin_r = 3 if Cin == 8 else Cin
         fl = 2.0 * N * Ho * Wo * k * k * cin_r * Cout
-        print(f"{name:34s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s   x{cnt:2d} = {ms*cnt:7.3f} ms")
-        tot += ms * cnt
-    print(f"weighted total {tot:.3f} ms")
+        cols = "  ".join(f"{ms*1e3:9.1f} us {fl/ms/1e9:7.1f} TF" for ms in best)
+        ratio = f"  B/A time {best[1]/best[0]:.3f}" if len(dbgs) > 1 else ""
+        print(f"{name:34s} {cols}   x{cnt:2d} = {best[0]*cnt:7.3f} ms{ratio}")
+        for v in range(len(dbgs)):
+            tot[v] += best[v] * cnt
+    print("weighted total " + "  ".join(f"{x:.3f} ms" for x in tot))
 
 
 if __name__ == "__main__":

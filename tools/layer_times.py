@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-layer kernel durations and inter-kernel gaps of the LAST pipeline pass in a
+`rocprofv3 --kernel-trace --output-format csv` trace of bench.py (default workload).
+
+    python tools/layer_times.py gpurun_out/kt/kt_kernel_trace.csv
+"""
+import csv
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frp_amd_loader  # noqa: E402,F401
+from frp_amd import netspec as ns  # noqa: E402
+
+
+def walk(layers, h0, w0, name, n):
+    dims = {name: (h0, w0)}
+    out = []
+    for l in layers:
+        h, w = dims[l.src]
+        flat = bool(l.flags & ns.FLAG_FLATTEN)
+        oh, ow = (1, 1) if flat else ns.out_hw(h, w, l.k, l.stride)
+        dims[l.dst] = (oh, ow)
+        fl = 2 * n * oh * ow * (l.cout_real or l.cout) * (l.cin_real or l.cin) * (1 if flat else l.k * l.k)
+        out.append((l, h, w, fl))
+    return out
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    frames, faces = 32, 320
+    starts = [i for i, r in enumerate(rows) if "stem_u8" in r["Kernel_Name"]]
+    seq = rows[starts[-1]:]
+    det = walk(ns.detector_layers(), 1088, 1920, "det.in", frames)
+    emb = walk(ns.iresnet_layers(), 112, 112, "emb.in", faces)
+    convs = iter(det[1:] + emb)
+    prev_end, t0, tot, tot_gap = None, int(seq[0]["Start_Timestamp"]), 0.0, 0.0
+    for r in seq:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = (s - prev_end) / 1e3 if prev_end else 0.0
+        prev_end = e
+        d = (e - s) / 1e3
+        tot += d
+        tot_gap += gap
+        name = r["Kernel_Name"]
+        if "conv_mfma" in name:
+            l, h, w, fl = next(convs)
+            cfg = re.search(r"<(\d+), (\d+),", name)
+            print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
+                  f"{d:8.1f} us  gap {gap:6.1f}  {fl / d / 1e6:7.1f} TF  tile {cfg.group(1)}x{cfg.group(2)}")
+        else:
+            print(f"{name[:57]:57s} grid {r['Grid_Size_X']:>9s} {d:8.1f} us  gap {gap:6.1f}")
+    print(f"sum of kernels {tot:.1f} us, sum of gaps {tot_gap:.1f} us, span {(prev_end - t0) / 1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
