@@ -45,7 +45,7 @@ def main():
         tot += d
         tot_gap += gap
         name = r["Kernel_Name"]
-        if "conv_mfma" in name:
+        if "conv_mfma" in name or "conv3x3_rows" in name:
             l, h, w, fl = next(convs)
             cfg = re.search(r"<(\d+), (\d+),", name)
             print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
