@@ -217,6 +217,94 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     const bool prelu = p.act == FRP_ACT_PRELU;
     const bool relu = p.act == FRP_ACT_RELU;
 
+    // ---------------- epilogue of tile ct (as in conv_mfma.hip): bias / border-class bias from the
+    // LDS parameter cache, residual, activation in fp32, 16-byte fp16 stores after a half-wave
+    // exchange; interior tiles take the unpredicated copy.
+    auto epilogue_body = [&](auto FULL_T, int m0, int c0) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(FULL_T)::value;
+        half4 r4[MP][MC][4];
+        bool mok[MP];
+        long obase[MP];
+        int cls[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int mraw = m0 + prow0 + i * 32 + fr;
+            mok[i] = FULL || mraw < p.M;
+            const int m = mok[i] ? mraw : 0;
+            long ridx = (long)m * p.Cout;
+            cls[i] = 0;
+            if (border || up2) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                if (border) cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+                if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+            }
+            obase[i] = (long)m * p.Cout;
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < MC; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                        r4[i][j][g] = *reinterpret_cast<const half4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                floatx4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                    } else if (prelu) {
+                        const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
+                    }
+                }
+                if (out32) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                        if (FULL || (mok[i] && co < p.Cout))
+                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
+                    }
+                } else {
+                    union { half4 h; unsigned u[2]; } pk[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                        swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                        const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                        if (FULL || (mok[i] && co < p.Cout))
+                            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
+                                make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
+                    }
+                }
+            }
+        }
+    };
+    auto run_epilogue = [&](int m0, int c0) __attribute__((always_inline)) {
+        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}, m0, c0); else epilogue_body(std::false_type{}, m0, c0);
+    };
+
     stamp(p.stamps, 1);
     for (int ct = t0; ct < t1; ++ct) {
 #pragma unroll
@@ -264,14 +352,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         if (FIRST) fetch_params(ct);                                                                  \
         read_frags(wsoff, KW, 0, 0);                                                                  \
         int cnt = 0;                                                                                  \
+        /* weight pieces first: their slack is two k-steps at best, the row patches have six */      \
         read_frags(wsoff, KW, 1, 1); mfma_group(0);                                                   \
-        if (x_live) { x_piece((KW) * 2 < 4 ? (KW) * 2 : 4); ++cnt; }                                  \
-        read_frags(wsoff, KW, 2, 0); mfma_group(1);                                                   \
-        if ((KW) < 2 && x_live) { x_piece((KW) * 2 + 1); ++cnt; }                                     \
-        read_frags(wsoff, KW, 3, 1); mfma_group(0);                                                   \
         if (w_live) { w_piece(0); ++cnt; }                                                            \
-        mfma_group(1);                                                                                \
         if (WI == 2 && w_live) { w_piece(WI - 1); ++cnt; }                                            \
+        read_frags(wsoff, KW, 2, 0); mfma_group(1);                                                   \
+        if (x_live) { x_piece((KW) * 2 < 4 ? (KW) * 2 : 4); ++cnt; }                                  \
+        read_frags(wsoff, KW, 3, 1); mfma_group(0);                                                   \
+        if ((KW) < 2 && x_live) { x_piece((KW) * 2 + 1); ++cnt; }                                     \
+        mfma_group(1);                                                                                \
         if ((KW) == 2 && x_live) advance_x();                                                         \
         if (w_live) advance_w();                                                                      \
         last_cnt = cnt;                                                                               \
@@ -295,91 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
 #undef ROWS_STEP
         if (ct == t0) stamp(p.stamps, 4);
 
-        // ---------------- epilogue of tile ct (as in conv_mfma.hip): bias / border-class bias from the
-        // LDS parameter cache, residual, activation in fp32, 16-byte fp16 stores after a half-wave
-        // exchange; interior tiles take the unpredicated copy.
-        auto epilogue_body = [&](auto FULL_T) {
-            constexpr bool FULL = decltype(FULL_T)::value;
-            half4 r4[MP][MC][4];
-            bool mok[MP];
-            long obase[MP];
-            int cls[MP];
-#pragma unroll
-            for (int i = 0; i < MP; ++i) {
-                const int mraw = m0 + prow0 + i * 32 + fr;
-                mok[i] = FULL || mraw < p.M;
-                const int m = mok[i] ? mraw : 0;
-                long ridx = (long)m * p.Cout;
-                cls[i] = 0;
-                if (border || up2) {
-                    int n, rem, oy, ox;
-                    fast_divmod(m, HoWo, inv_howo, n, rem);
-                    fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                    if (border) cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-                    if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
-                }
-                obase[i] = (long)m * p.Cout;
-                if (has_res) {
-#pragma unroll
-                    for (int j = 0; j < MC; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                            r4[i][j][g] = *reinterpret_cast<const half4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
-                        }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MP; ++i) {
-#pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    floatx4 v[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
-                        const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
-                        if (has_res) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
-                        } else if (prelu) {
-                            const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
-                        }
-                    }
-                    if (out32) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                            if (FULL || (mok[i] && co < p.Cout))
-                                *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
-                        }
-                    } else {
-                        union { half4 h; unsigned u[2]; } pk[4];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
-                            swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
-                            const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
-                            if (FULL || (mok[i] && co < p.Cout))
-                                *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
-                                    make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
-                        }
-                    }
-                }
-            }
-        };
-        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}); else epilogue_body(std::false_type{});
+        run_epilogue(m0, c0);
         if (ct == t0) stamp(p.stamps, 5);
     }
     stamp(p.stamps, 6);

@@ -63,6 +63,8 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
     if (r >= d) { ++q; r -= d; }
 }
 
+__device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -27,8 +27,11 @@
 //   * the LDS image is rows of 128 B with chunk ^= (row>>1)&7 (conflict-free for the
 //     ds_read_b128 fragment reads); the DMA destination is lane-linear, so the swizzle is
 //     applied to the per-lane SOURCE chunk;
-//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of
-//     tiles and the cout tiles of one pixel tile run back to back on the same L2.
+//   * each persistent workgroup walks a contiguous range of tiles with the cout tiles of one pixel
+//     tile back to back, and k runs (64-channel block, kh, kw): the nine taps of a channel block
+//     re-read nearly the same input lines within nine consecutive k-steps, so they hit in L2
+//     (tap-major order thrashed the 4 MiB L2 on Cin >= 128: 2-10x the algorithmic reads);
+//   * 3x3 stride-1 layers with Cin % 64 == 0 go to conv3x3_rows.hip (row patches) instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -38,7 +41,7 @@
 namespace frp {
 
 template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XB = TP * 128;              // bytes of one X stage
     constexpr int WB = TC * 128;
@@ -83,7 +86,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
     unsigned woff[WI];     // byte offset of (cout row, k=chunk); rows >= Cout are out of range -> zeros
     int kh = 0, kw = 0, cb = 0;               // aligned path: uniform (tap, 64-channel block) walk
     const int cpt = p.Cin >> 6;
-    const bool tap_major = p.dbg & 8;         // A/B: the old (tap, channel block) K order
     int it = t0, iks = 0, ibuf = 0;           // issue cursor: tile, k-step, ring slot
     int iks_base = 0;                         // first k-step of the issue cursor's slice
     auto setup_issue_tile = [&](int vtile) {
@@ -123,17 +125,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
         }
         if constexpr (!SMALL) {                  // start of the slice in the (channel block, tap) walk
             const int taps = p.KS * p.KS;
-            if (tap_major) {
-                const int tap = iks_base / cpt;
-                cb = iks_base - tap * cpt;
-                kh = tap / p.KS;
-                kw = tap - kh * p.KS;
-            } else {
-                cb = iks_base / taps;
-                const int tap = iks_base - cb * taps;
-                kh = tap / p.KS;
-                kw = tap - kh * p.KS;
-            }
+            cb = iks_base / taps;
+            const int tap = iks_base - cb * taps;
+            kh = tap / p.KS;
+            kw = tap - kh * p.KS;
         }
     };
 
@@ -150,11 +145,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_mfma_kernel(C
             st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
             st_bit = 1u << (kh * 3 + kw);
             st_wadd = (unsigned)(((kh * p.KS + kw) * cpt + cb) << 7);
-            if (tap_major) {
-                if (++cb == cpt) { cb = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
-            } else {
-                if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cb; } }
-            }
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cb; } }
         } else {
             const int kg = (ks << 6) + lchunk * 8;
             const int tap = kg >> p.cin_shift;
@@ -538,20 +529,11 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one
     //               workgroup per CU).  Two independent 4-wave 128x128 groups per CU (2-slot
     //               rings) were 20-25 % slower; a 128x64 per-wave tile does not fit 256 VGPRs.
-    //               dbg 16 (conv_bench only) selects the 4-wave variant for A/B runs.
-    //   Cout <= 64: see below.
-    const int force = p.dbg >> 4;
-    if (p.Cout > 64) {
-        if (force == 1)
-            return small ? launch_cfg<128, 128, 2, 2, 2, 4, true>(p, stream) : launch_cfg<128, 128, 2, 2, 2, 4, false>(p, stream);
+    //   Cout <= 64: 256 x 64, 8 waves (32x64 each), 3-slot ring (a 512 x 64 tile with 64x64 per wave
+    //               measured 10 % slower, two co-resident 4-wave 128 x 64 groups 0-4 % slower).
+    if (p.Cout > 64)
         return small ? launch_cfg<256, 128, 4, 2, 3, 8, true>(p, stream) : launch_cfg<256, 128, 4, 2, 3, 8, false>(p, stream);
-    } else {
-        // narrow layers: 256 x 64, 8 waves (32x64 each), 3-slot ring (a 512 x 64 tile with 64x64
-        // per wave measured 10 % slower: these 9-step layers are bound by per-tile overheads)
-        if (force == 2)
-            return small ? launch_cfg<128, 64, 4, 1, 3, 4, true>(p, stream) : launch_cfg<128, 64, 4, 1, 3, 4, false>(p, stream);
-        return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
-    }
+    return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
 }
 
 // Split-K factor for a skinny GEMM-shaped conv (the 25088 -> 512 FC: 8 output tiles but 392

@@ -29,8 +29,7 @@ struct ConvParams {
     int Hr, Wr;             // residual spatial dims (RES_UP2)
     int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
-    int dbg;                // A/B switches (conv_bench only): 1 = generic kernel for row-patch shapes, 8 = tap-major k order,
-                            // 16 / 32 = alternative tile configurations
+    int dbg;                // A/B switch (tests, conv_bench): 1 = generic kernel also for row-patch shapes
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
     unsigned x_bytes, w_bytes;   // buffer-descriptor sizes (each < 2 GiB)
