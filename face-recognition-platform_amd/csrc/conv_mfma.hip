@@ -173,11 +173,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
 #define DMA_PIECE(bufv, j)                                                                              \
     do {                                                                                                \
         if constexpr ((j) < LPS) {                                                                      \
+            constexpr int jo_ = (j) < WI ? (j) + XI : (j) - WI;   /* weight pieces first: +2 % */            \
             unsigned char* base_ = smem + (bufv) * STAGE;                                               \
-            if constexpr ((j) < XI)                                                                     \
-                dma16(xrsrc, base_ + ((j) * NW + wave) * 1024, x_off((j) < XI ? (j) : 0));         \
+            if constexpr (jo_ < XI)                                                                     \
+                dma16(xrsrc, base_ + (jo_ * NW + wave) * 1024, x_off(jo_ < XI ? jo_ : 0));              \
             else                                                                                        \
-                dma16(wrsrc, base_ + XB + (((j) - XI) * NW + wave) * 1024, w_off((j) >= XI && (j) < LPS ? (j) - XI : 0)); \
+                dma16(wrsrc, base_ + XB + ((jo_ - XI) * NW + wave) * 1024, w_off(jo_ >= XI && jo_ < LPS ? jo_ - XI : 0)); \
         }                                                                                               \
     } while (0)
     // pieces [lo, hi) with lo, hi compile-time constants and hi - lo <= 6
