@@ -1009,8 +1009,38 @@ static int match_common(frp_handle* h, const float* q, int M, float* all_scores_
 int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* idx, float* cos) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    if (topk != 1) return fail(h, FRP_ERR_INVALID, "topk must be 1");
-    return match_common(h, q, M, nullptr, idx, cos);
+    if (topk < 1 || topk > FRP_MAX_TOPK) return fail(h, FRP_ERR_INVALID, "topk must be in 1..FRP_MAX_TOPK");
+    if (topk == 1) return match_common(h, q, M, nullptr, idx, cos);
+    // k > 1: score matrix on the device (query chunks of <= 1 GiB of scores), then k selection passes per row
+    if (!q || !idx || !cos || M <= 0 || M > (1 << 20)) return fail(h, FRP_ERR_INVALID, "bad query arguments");
+    if (h->g_rows <= 0) return fail(h, FRP_ERR_NO_GALLERY, "gallery is empty");
+    const long N = h->g_rows;
+    int chunk = (int)std::max<long>(1, std::min<long>(M, (1L << 28) / N));
+    DevBuf all, didx, dcos;
+    int rc = ensure(h, all, (size_t)chunk * N * 4);
+    if (rc == FRP_OK) rc = ensure(h, didx, (size_t)chunk * topk * 4);
+    if (rc == FRP_OK) rc = ensure(h, dcos, (size_t)chunk * topk * 4);
+    hipError_t e = hipSuccess;
+    for (int m0 = 0; rc == FRP_OK && e == hipSuccess && m0 < M; m0 += chunk) {
+        const int m = std::min(chunk, M - m0);
+        const int mpad = round_up(m, 32);
+        rc = ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2);
+        if (rc != FRP_OK) break;
+        e = hipMemsetAsync(h->q16.p, 0, (size_t)mpad * FRP_EMB_DIM * 2, h->stream);
+        if (e != hipSuccess) break;
+        rc = upload_rows_normalized(h, q + (size_t)m0 * FRP_EMB_DIM, m, (_Float16*)h->q16.p);
+        if (rc == FRP_OK) rc = run_match(h, m, (float*)all.p);
+        if (rc != FRP_OK) break;
+        e = launch_topk_rows((const float*)all.p, m, N, topk, (int32_t*)didx.p, (float*)dcos.p, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(idx + (size_t)m0 * topk, didx.p, (size_t)m * topk * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(cos + (size_t)m0 * topk, dcos.p, (size_t)m * topk * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    release(all); release(didx); release(dcos);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("match top-k: ") + hipGetErrorString(e));
+    return FRP_OK;
 }
 
 int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all) {

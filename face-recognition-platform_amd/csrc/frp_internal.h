@@ -124,5 +124,7 @@ struct MatchParams {
 };
 int match_num_workgroups(long N);
 hipError_t launch_match(const MatchParams& p, hipStream_t stream);
+// top-k of each row of a device score matrix [M x N] by (cosine desc, row asc); -1 / -2.0 beyond N entries
+hipError_t launch_topk_rows(const float* scores, int M, long N, int k, int32_t* idx_out, float* cos_out, hipStream_t stream);
 
 }  // namespace frp

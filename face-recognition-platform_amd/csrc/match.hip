@@ -153,4 +153,56 @@ hipError_t launch_match(const MatchParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Top-k per query row of a device score matrix [M x N], ordered by (cosine descending, row ascending):
+// the order of the oracle's stable argsort and of the fused top-1.  One workgroup per query; pass r
+// takes the best element strictly AFTER the (r-1)-th in that total order, so k coalesced passes over
+// the row (N*4 bytes each, from L2/MALL for N <= a few million) and no per-thread candidate lists.
+// Replaces np.argpartition + argsort over face_distance (backend/app/services/face_service.py:599-603).
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, long N, int k,
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ cos_out) {
+    __shared__ float sc[4];
+    __shared__ int si[4];
+    const float* s = scores + (long)blockIdx.x * N;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float prev_c = __builtin_inff();
+    int prev_i = -1;
+    for (int r = 0; r < k; ++r) {
+        float bc = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (long j = t; j < N; j += 256) {
+            const float c = s[j];
+            const bool after_prev = (c < prev_c) || (c == prev_c && (int)j > prev_i);
+            if (after_prev && (c > bc || (c == bc && (int)j < bi))) { bc = c; bi = (int)j; }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const float oc = __shfl_down(bc, off);
+            const int oi = __shfl_down(bi, off);
+            if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+        }
+        if (lane == 0) { sc[wave] = bc; si[wave] = bi; }
+        __syncthreads();
+        if (t == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (sc[w] > bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
+            const bool found = bi != 0x7fffffff;
+            idx_out[(long)blockIdx.x * k + r] = found ? bi : -1;
+            cos_out[(long)blockIdx.x * k + r] = found ? bc : -2.0f;
+            sc[0] = found ? bc : -__builtin_inff();
+            si[0] = found ? bi : 0x7fffffff;
+        }
+        __syncthreads();
+        prev_c = sc[0];
+        prev_i = si[0];
+        __syncthreads();
+    }
+}
+
+hipError_t launch_topk_rows(const float* scores, int M, long N, int k, int32_t* idx_out, float* cos_out, hipStream_t stream) {
+    if (!scores || !idx_out || !cos_out || M <= 0 || N <= 0 || N > 0x7fffff00L || k <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(M), dim3(256), 0, stream, scores, N, k, idx_out, cos_out);
+    return hipGetLastError();
+}
+
 }  // namespace frp

@@ -456,15 +456,25 @@ class FaceService:
         return clusters
 
     def find_k_nearest(self, test_encoding: np.ndarray, k: int = 5) -> List[Dict[str, Any]]:
-        if len(self.ENCODINGS) == 0:
+        """face_service.py:590-612 with the distance pass AND the k-selection on the device (ties: the
+        earlier gallery row first; the reference's argpartition leaves tie order unspecified)."""
+        n = len(self.ENCODINGS)
+        if n == 0:
             return []
-        targets, distances = self._distances(test_encoding)
-        k = min(k, len(distances))
-        idx = np.argpartition(distances, k - 1)[:k]
-        idx = idx[np.argsort(distances[idx])]
-        return [{"target": targets[int(i)], "distance": float(distances[int(i)]),
-                 "confidence": confidence_level(float(distances[int(i)])),
-                 "confidence_score": calibrate_confidence(float(distances[int(i)]))} for i in idx]
+        k = min(int(k), n)
+        if k < 1:
+            return []
+        if k > native.MAX_TOPK:                      # beyond the device limit: full score row + host selection
+            targets, distances = self._distances(test_encoding)
+            idx = np.argsort(distances, kind="stable")[:k]
+            pairs = [(targets[int(i)], float(distances[int(i)])) for i in idx]
+        else:
+            q = np.asarray(test_encoding, dtype=np.float32).reshape(1, -1)
+            rows, cos = self._eng().match(q, topk=k)
+            rows, cos = np.atleast_2d(rows)[0], np.atleast_2d(cos)[0]
+            pairs = [(self.ENCODINGS.name_of_row(int(r)), float(cos_to_distance(float(c)))) for r, c in zip(rows, cos) if r >= 0]
+        return [{"target": t, "distance": d, "confidence": confidence_level(d),
+                 "confidence_score": calibrate_confidence(d)} for t, d in pairs]
 
     # ------------------------------------------------------------------ streaming entry points (new)
     def process_frames(self, frames_bgr: np.ndarray, max_faces: int = 10, threshold: Optional[float] = None,

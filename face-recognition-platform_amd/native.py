@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfrp.so")
 EMB_DIM = 512
 CHIP = 112
 MAX_FACES_CAP = 128
+MAX_TOPK = 64
 FLAG_FORCED_K, FLAG_RGB, FLAG_NO_MATCH = 1, 2, 4
 F32, F16, F64 = 0, 1, 2
 
@@ -320,11 +321,14 @@ class Engine:
         self._chk(self._lib.frp_embed_faces(self._h, _ptr(frames), H, W, rs, _ptr(k), k.shape[0], flags, _ptr(out)))
         return out
 
-    def match(self, q: np.ndarray):
+    def match(self, q: np.ndarray, topk: int = 1):
+        """-> (row idx, cosine): [M] for topk == 1, else [M, topk] ordered by (cosine desc, row asc);
+        columns beyond the gallery size hold -1 / -2.0"""
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, EMB_DIM)
-        idx = np.empty((q.shape[0],), np.int32)
-        cos = np.empty((q.shape[0],), np.float32)
-        self._chk(self._lib.frp_match(self._h, _ptr(q), q.shape[0], 1, _ptr(idx), _ptr(cos)))
+        shape = (q.shape[0],) if topk == 1 else (q.shape[0], topk)
+        idx = np.empty(shape, np.int32)
+        cos = np.empty(shape, np.float32)
+        self._chk(self._lib.frp_match(self._h, _ptr(q), q.shape[0], int(topk), _ptr(idx), _ptr(cos)))
         return idx, cos
 
     def match_scores(self, q: np.ndarray) -> np.ndarray:

@@ -31,7 +31,8 @@ extern "C" {
 #define FRP_EMB_DIM 512      /* embedding width (reference: 128-d dlib, face_service.py:179) */
 #define FRP_CHIP 112         /* aligned face chip edge */
 #define FRP_KPS 5            /* landmarks per face */
-#define FRP_MAX_FACES_CAP 128/* upper bound for max_faces per frame */
+#define FRP_MAX_FACES_CAP 128
+#define FRP_MAX_TOPK 64/* upper bound for max_faces per frame */
 
 typedef enum frp_status {
     FRP_OK = 0,
@@ -167,8 +168,9 @@ int frp_embed_aligned(frp_handle* h, const uint8_t* chips, int32_t M, float* emb
 /* landmarks on one frame -> unit embeddings [M,512] (face_encodings with known faces) */
 int frp_embed_faces(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int64_t row_stride,
                     const float* kps, int32_t M, uint32_t flags, float* emb);
-/* cosine top-1 (topk must be 1 in this version) of M unit queries vs the gallery
- * -> face_recognition.face_distance + argmin (face_service.py:410,599-603) */
+/* cosine top-k (1 <= topk <= FRP_MAX_TOPK) of M queries vs the gallery, ordered by (cosine descending, row
+ * ascending): idx / cos are [M x topk]; entries beyond the gallery size are -1 / -2.0
+ * -> face_recognition.face_distance + argmin / argpartition (face_service.py:410,599-603) */
 int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* idx, float* cos);
 /* all cosines [M x N] (the N-dict compat path of compare_faces, face_service.py:409-432) */
 int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all);

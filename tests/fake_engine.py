@@ -44,6 +44,16 @@ class FakeEngine:
         q = q / np.linalg.norm(q, axis=1, keepdims=True)
         return q @ self.G.T
 
+    def match(self, q, topk=1):
+        S = self.match_scores(q)
+        idx = np.argsort(-S, axis=1, kind="stable")[:, :topk]
+        cos = np.take_along_axis(S, idx, axis=1)
+        if topk > S.shape[1]:
+            pad = topk - S.shape[1]
+            idx = np.concatenate([idx, np.full((len(S), pad), -1)], axis=1)
+            cos = np.concatenate([cos, np.full((len(S), pad), -2.0)], axis=1)
+        return (idx[:, 0], cos[:, 0]) if topk == 1 else (idx.astype(np.int32), cos)
+
     def process_frames(self, frames, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
         return self.canned
 

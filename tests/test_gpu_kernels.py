@@ -257,3 +257,43 @@ def test_detector_head_maps_parity(engine):
         err = np.abs(g[..., :30].astype(np.float32) - r).max()
         assert err < 2e-2 * scale, (err, scale)
         assert np.all(g[..., 30:] == 0)
+
+
+@pytest.mark.parametrize("N,M,k", [(1000, 5, 7), (4097, 3, 64), (5, 2, 8), (100000, 4, 10)])
+def test_match_topk_parity(engine, N, M, k):
+    """device top-k (a12, find_k_nearest): same rows in the same order as the oracle's stable argsort
+    computed on the fp16-rounded operands the device holds; duplicate rows exercise the tie rule."""
+    rng = np.random.default_rng(N + 31 * k)
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    if N >= 1000:
+        G[700] = G[3]                       # exact duplicates: the lower row must come first
+        G[701] = G[3]
+    Q = G[rng.integers(0, N, size=M)] + 0.3 * rng.standard_normal((M, 512)).astype(np.float32) / np.sqrt(512)
+    if N >= 1000:
+        Q[0] = G[3]
+    engine.gallery_set(G)
+    idx, cos = engine.match(Q, topk=k)
+    assert idx.shape == (M, k) and cos.shape == (M, k)
+    S = engine.match_scores(Q)              # the device's own score matrix: selection must be exact on it
+    kk = min(k, N)
+    oidx = np.argsort(-S.astype(np.float64), axis=1, kind="stable")[:, :kk]
+    assert np.array_equal(idx[:, :kk], oidx)
+    assert np.array_equal(cos[:, :kk], np.take_along_axis(S, oidx, axis=1))
+    assert np.all(idx[:, kk:] == -1) and np.all(cos[:, kk:] == -2.0)
+    # and against the fp64 oracle on the original operands: same identities where the margin exceeds fp16 noise
+    o2, c2 = onet.match_topk(G, Q / np.linalg.norm(Q, axis=1, keepdims=True), kk)
+    assert np.abs(cos[:, :kk] - c2).max() < 3e-3
+    i1, c1 = engine.match(Q)                # top-1 path agrees with column 0
+    assert np.array_equal(i1, idx[:, 0])
+    if N >= 1000:
+        assert list(idx[0, :3]) == [3, 700, 701]
+
+
+def test_match_topk_rejects_bad_k(engine):
+    from frp_amd.native import FrpError
+    engine.gallery_set(np.eye(4, 512, dtype=np.float32))
+    with pytest.raises(FrpError):
+        engine.match(np.ones((1, 512), np.float32), topk=0)
+    with pytest.raises(FrpError):
+        engine.match(np.ones((1, 512), np.float32), topk=65)
