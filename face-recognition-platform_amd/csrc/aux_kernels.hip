@@ -80,11 +80,13 @@ hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int
 __constant__ float kTemplate[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f,
                                     41.5493f, 92.3655f, 70.7299f, 92.2041f};
 
-// One workgroup per face.  Least-squares similarity (closed form of the 2-D Umeyama
+// ALIGN_SPLIT workgroups per face (16 chip rows each: 320 faces alone would put 5 waves on a CU and
+// leave the gather latency-bound).  Least-squares similarity (closed form of the 2-D Umeyama
 // problem: scaled rotation [[a,-b],[b,a]] + t) in double, inverse map per output pixel in
 // fp32, float bilinear with constant-0 border, RGB (x-127.5)/127.5 -> fp16 NHWC8.
+#define ALIGN_SPLIT 7
 __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
-    const int f = blockIdx.x;
+    const int f = blockIdx.x / ALIGN_SPLIT, part = blockIdx.x - f * ALIGN_SPLIT;
     if (f >= p.n_faces) return;
     const int slot = p.face_slot ? p.face_slot[f] : f;
     const int b = p.face_slot ? slot / p.max_faces : 0;
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
     const uint8_t* img = p.frames + (long)b * p.frame_stride;
     _Float16* out = p.chips + (long)f * (FRP_CHIP_PIX * 8);
     const int c_r = p.rgb_in ? 0 : 2, c_b = p.rgb_in ? 2 : 0;
-    for (int i = threadIdx.x; i < FRP_CHIP_PIX; i += blockDim.x) {
+    constexpr int kPart = FRP_CHIP_PIX / ALIGN_SPLIT;      // 1792 pixels = 16 rows
+    static_assert(kPart * ALIGN_SPLIT == FRP_CHIP_PIX, "chip rows must split evenly");
+    for (int i = part * kPart + threadIdx.x; i < (part + 1) * kPart; i += blockDim.x) {
         const int v = i / 112, u = i - v * 112;
         const float sx = i00 * (float)u + i01 * (float)v + itx;
         const float sy = i10 * (float)u + i11 * (float)v + ity;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
 hipError_t launch_align(const AlignParams& p, hipStream_t stream) {
     if (p.n_faces <= 0) return hipSuccess;
     if (!p.frames || !p.kps || !p.chips || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(align_kernel, dim3(p.n_faces), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(align_kernel, dim3(p.n_faces * ALIGN_SPLIT), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -172,7 +176,7 @@ hipError_t launch_chips_to_blob(const uint8_t* chips, int M, _Float16* out, hipS
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ K5 tail: one wave per row
+// ------------------------------------------------------------------ K5 tail: one workgroup per row
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -181,33 +185,48 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _Float16* __restrict__ emb16, int M, int D,
                                                       const float* __restrict__ partials, int ksplit, const float* __restrict__ bias) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= M) return;
+    // one workgroup per row (D <= 1024: up to 4 elements per thread in registers)
+    __shared__ float wsum[4];
+    const int row = blockIdx.x, t = threadIdx.x;
     float* e = emb + (long)row * D;
-    if (partials) {                       // split-K FC: reduce the slabs (+ folded bias) first
-        for (int i = lane; i < D; i += 64) {
-            float v = bias[i];
-            for (int s = 0; s < ksplit; ++s) v += partials[((long)s * M + row) * D + i];
-            e[i] = v;
+    float v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = t + q * 256;
+        v[q] = 0.f;
+        if (i < D) {
+            if (partials) {               // split-K FC: reduce the slabs (+ folded bias) first
+                float a = bias[i];
+                for (int s = 0; s < ksplit; ++s) a += partials[((long)s * M + row) * D + i];
+                v[q] = a;
+            } else {
+                v[q] = e[i];
+            }
+            ss += v[q] * v[q];
         }
     }
-    float ss = 0.f;
-    for (int i = lane; i < D; i += 64) ss += e[i] * e[i];
     ss = wave_sum(ss);
+    if ((t & 63) == 0) wsum[t >> 6] = ss;
+    __syncthreads();
+    ss = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     const float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
-    for (int i = lane; i < D; i += 64) {
-        const float v = e[i] * inv;
-        e[i] = v;
-        if (emb16) emb16[(long)row * D + i] = (_Float16)v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = t + q * 256;
+        if (i < D) {
+            const float o = v[q] * inv;
+            e[i] = o;
+            if (emb16) emb16[(long)row * D + i] = (_Float16)o;
+        }
     }
 }
 
 hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream, const float* partials, int ksplit,
                          const float* bias) {
     if (M <= 0) return hipSuccess;
-    if (partials && (ksplit <= 0 || !bias)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l2norm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, emb, emb16, M, D, partials, ksplit, bias);
+    if (D <= 0 || D > 1024 || (partials && (ksplit <= 0 || !bias))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(M), dim3(256), 0, stream, emb, emb16, M, D, partials, ksplit, bias);
     return hipGetLastError();
 }
 

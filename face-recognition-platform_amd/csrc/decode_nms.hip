@@ -1,4 +1,5 @@
-// K3: anchor decode + candidate selection + ordering + greedy NMS, one workgroup per frame.
+// K3: anchor decode + candidate selection + ordering + greedy NMS: a chip-wide logit gather, then one
+// workgroup per frame.
 //
 // Replaces the tail of face_recognition.face_locations (backend/app/routes/camera.py:232,
 // backend/app/services/face_service.py:156) and the caller's cap `face_locations[:max_faces]`
@@ -44,6 +45,30 @@ __device__ __forceinline__ const _Float16* anchor_ptr(const FrameView& fv, int i
     return base + (long)pos * 32 + a * 15;
 }
 
+__device__ __forceinline__ FrameView frame_view(const DecodeParams& p, int b, int& A) {
+    FrameView fv;
+    fv.h0 = p.head[0] + (long)b * p.hl[0] * p.wl[0] * 32;
+    fv.h1 = p.head[1] + (long)b * p.hl[1] * p.wl[1] * 32;
+    fv.h2 = p.head[2] + (long)b * p.hl[2] * p.wl[2] * 32;
+    fv.w0 = p.wl[0]; fv.w1 = p.wl[1]; fv.w2 = p.wl[2];
+    fv.e0 = p.hl[0] * p.wl[0] * 2;
+    fv.e1 = fv.e0 + p.hl[1] * p.wl[1] * 2;
+    A = fv.e1 + p.hl[2] * p.wl[2] * 2;
+    return fv;
+}
+
+// The logits sit at a 30- or 34-byte stride inside 64-byte location rows: this chip-wide pass gathers
+// them once into a dense per-frame array (171 KB at 1080p, L2-resident) that the per-frame workgroup
+// below counts / selects / gathers from, instead of one workgroup dragging 5.5 MB of sectors per frame.
+__global__ __launch_bounds__(256) void gather_logits_kernel(DecodeParams p) {
+    int A;
+    const FrameView fv = frame_view(p, blockIdx.y, A);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A) return;
+    int lv, x, y;
+    p.logits[(long)blockIdx.y * A + i] = anchor_ptr(fv, i, lv, x, y)[0];
+}
+
 __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
     __shared__ unsigned long long keys[NMS_CAP];
     __shared__ int hist[4096];
@@ -55,31 +80,16 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    FrameView fv;
-    fv.h0 = p.head[0] + (long)b * p.hl[0] * p.wl[0] * 32;
-    fv.h1 = p.head[1] + (long)b * p.hl[1] * p.wl[1] * 32;
-    fv.h2 = p.head[2] + (long)b * p.hl[2] * p.wl[2] * 32;
-    fv.w0 = p.wl[0]; fv.w1 = p.wl[1]; fv.w2 = p.wl[2];
-    fv.e0 = p.hl[0] * p.wl[0] * 2;
-    fv.e1 = fv.e0 + p.hl[1] * p.wl[1] * 2;
-    const int A = fv.e1 + p.hl[2] * p.wl[2] * 2;
+    int A;
+    const FrameView fv = frame_view(p, b, A);
     const float lt = p.logit_thresh;
 
     // ---- pass 0: count candidates
     if (tid == 0) { s_cnt = 0; s_keepn = 0; }
     __syncthreads();
-    // The logits sit at a 30- or 34-byte stride inside 64-byte location rows; this first pass
-    // gathers them once into a dense per-frame array (171 KB at 1080p, L2-resident) that the
-    // select / gather passes below re-read instead of dragging the whole head maps through again.
-    _Float16* dense = p.logits + (long)b * A;
+    const _Float16* dense = p.logits + (long)b * A;     // written by gather_logits_kernel
     int local = 0;
-    for (int i = tid; i < A; i += NT) {
-        int lv, x, y;
-        const _Float16* q = anchor_ptr(fv, i, lv, x, y);
-        const _Float16 lg = q[0];
-        dense[i] = lg;
-        local += ((float)lg >= lt) ? 1 : 0;
-    }
+    for (int i = tid; i < A; i += NT) local += ((float)dense[i] >= lt) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((tid & 63) == 0) atomicAdd(&s_cnt, local);
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
             for (int i = tid; i < 4096; i += NT) hist[i] = 0;
             __syncthreads();
             for (int i = tid; i < A; i += NT) {
-                const _Float16 lg = dense[i];      // written by this same thread in pass 0
+                const _Float16 lg = dense[i];
                 if ((float)lg >= lt) {
                     const unsigned long long k = ((unsigned long long)sortable16(__builtin_bit_cast(unsigned short, lg)) << 20) |
                                                  (unsigned long long)(0xFFFFF - i);
@@ -287,6 +297,9 @@ hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream) {
     }
     if (A > 0xFFFFF) return hipErrorInvalidValue;   // 20-bit anchor index in the sort key
     if (!p.boxes || !p.kps || !p.scores || !p.counts || !p.logits) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_logits_kernel, dim3((unsigned)((A + 255) / 256), p.B), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(decode_nms_kernel, dim3(p.B), dim3(NT), 0, stream, p);
     return hipGetLastError();
 }
