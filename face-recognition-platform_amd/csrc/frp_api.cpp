@@ -166,13 +166,56 @@ bool stem_fusable(const Net& net) {
            op.act == FRP_ACT_RELU && op.res_buf < 0 && (op.flags & ~0) == 0 && (op.real_ch & 0xffff) == 3;
 }
 
+// ... and the second one (3x3 s2 32->64 + ReLU) reading nothing but the first: both stems in one kernel
+bool stem12_fusable(const Net& net) {
+    if (!stem_fusable(net) || net.ops.size() < 2) return false;
+    const frp_conv_op& a = net.ops[0];
+    const frp_conv_op& b = net.ops[1];
+    if (!(b.in_buf == a.out_buf && b.cin == 32 && b.cout == 64 && b.ksize == 3 && b.stride == 2 && b.act == FRP_ACT_RELU &&
+          b.res_buf < 0 && b.flags == 0))
+        return false;
+    for (size_t i = 2; i < net.ops.size(); ++i)          // the stem1 map must have no other reader
+        if (net.ops[i].in_buf == a.out_buf || net.ops[i].res_buf == a.out_buf) {
+            // (physical buffers are recycled: a later tensor may live in the same buffer - only a read
+            // before the next write of that buffer would be the stem1 map)
+            bool rewritten = false;
+            for (size_t j = 2; j < i; ++j) rewritten |= net.ops[j].out_buf == a.out_buf;
+            if (!rewritten) return false;
+        }
+    return true;
+}
+
 int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr) {
     // dims are re-derived while walking (physical buffers are reused by several tensors)
     std::vector<TensorDims> d(net.n_bufs);
     d[net.in_buf] = {H, W, net.in_ch, false};
     const char* wbase = (const char*)h->wdata.p;
     bool first = true;
+    size_t skip = 0;
+    // both detector stems in one kernel (the stem1 map never reaches HBM); FRP_NO_FUSED_STEM12=1 keeps
+    // stem1 (fused with the u8 normalisation) and stem2 (generic conv) apart for A/B runs
+    if (stem && stem12_fusable(net) && (stem->Hc % 4) == 0 && (stem->Wc % 4) == 0 && !getenv("FRP_NO_FUSED_STEM12")) {
+        const frp_conv_op& a = net.ops[0];
+        const frp_conv_op& b = net.ops[1];
+        Stem12Params sp{};
+        sp.frames = stem->frames; sp.B = stem->B; sp.H = stem->H; sp.W = stem->W;
+        sp.row_stride = stem->row_stride; sp.frame_stride = stem->frame_stride;
+        sp.Hc = stem->Hc; sp.Wc = stem->Wc; sp.Ho1 = stem->Hc / 2; sp.Wo1 = stem->Wc / 2; sp.Ho2 = stem->Hc / 4; sp.Wo2 = stem->Wc / 4;
+        sp.rgb_in = stem->rgb_in;
+        sp.w1 = (const _Float16*)(wbase + a.w_off); sp.bias1 = (const float*)(wbase + a.bias_off);
+        sp.w2 = (const _Float16*)(wbase + b.w_off); sp.bias2 = (const float*)(wbase + b.bias_off);
+        sp.out = (_Float16*)net.bufs[b.out_buf].p;
+        hipError_t e = launch_stem12_u8(sp, h->stream);
+        if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_stem12_u8: ") + hipGetErrorString(e));
+        d[a.out_buf] = {sp.Ho1, sp.Wo1, 32, false};
+        d[b.out_buf] = {sp.Ho2, sp.Wo2, 64, false};
+        *flops += 2.0 * batch * sp.Ho1 * sp.Wo1 * 9.0 * 3 * 32 + 2.0 * batch * sp.Ho2 * sp.Wo2 * 9.0 * 32 * 64;
+        *launches += 1;
+        skip = 2;
+        first = false;
+    }
     for (const frp_conv_op& op : net.ops) {
+        if (skip) { --skip; continue; }
         if (first && stem) {
             first = false;
             StemParams sp = *stem;

@@ -59,6 +59,23 @@ struct StemParams {
 };
 hipError_t launch_stem_u8(const StemParams& p, hipStream_t stream);
 
+// K1+K2+K2 fused detector stems: u8 frames -> conv3x3 s2 (3->32) + ReLU -> conv3x3 s2 (32->64) + ReLU
+struct Stem12Params {
+    const uint8_t* frames;   // [B,H,W,3] u8
+    int B, H, W;
+    long row_stride, frame_stride;
+    int Hc, Wc;              // letterbox canvas (multiples of 32)
+    int Ho1, Wo1;            // stem1 map: Hc/2, Wc/2
+    int Ho2, Wo2;            // stem2 map: Hc/4, Wc/4
+    int rgb_in;
+    const _Float16* w1;      // folded [32][3][3][8] fp16 (channels R,G,B,0..)
+    const float* bias1;      // [32]
+    const _Float16* w2;      // folded [64][3][3][32] fp16
+    const float* bias2;      // [64]
+    _Float16* out;           // [B,Ho2,Wo2,64]
+};
+hipError_t launch_stem12_u8(const Stem12Params& p, hipStream_t stream);
+
 // K3: decode + candidate select + sort + NMS, one workgroup per frame
 struct DecodeParams {
     const _Float16* head[3];   // per stride [B, H_l, W_l, 32]

@@ -146,6 +146,261 @@ __global__ __launch_bounds__(256) void stem_u8_kernel(StemParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1+K2+K2 fused: u8 frames -> stem1 (3x3 s2, 3->32, ReLU) -> stem2 (3x3 s2, 32->64, ReLU), fp16 NHWC64
+// out.  Neither the normalised blob (1.07 GB per 32 x 1080p) nor the stem1 activation (another 1.07 GB
+// written and re-read 1.4x) ever reaches HBM: 0.2 GB of frames in, 0.53 GB out.
+//
+// Persistent workgroups (4 waves) walk stem2 output tiles of 4 rows x 32 columns:
+//   A. the 19 x 131-pixel u8 patch is normalised once into LDS (fp16, RGB order), as in stem_u8_kernel;
+//   B. stem1 for the 9 x 65 halo'd tile (18 jobs of 32 pixels + one for the 65th column): one MFMA per
+//      kernel row (K laid out as 3 x 16, see above),
+//      bias + ReLU, positions outside the stem1 map forced to 0 (they are stem2's zero padding), result
+//      to LDS as [row][column parity][column/2][32 ch] with an 80-byte pixel pitch: a stem2 tap reads
+//      every second stem1 column, so with the parity split the 32 lanes of a fragment read walk
+//      consecutive 80-byte slots - conflict-free for ds_read_b128 (64 B pitch: 8-way);
+//   C. stem2: wave w owns cout group w&1 and output rows 2*(w>>1)+{0,1}; its 18 A fragments (9 taps x
+//      2 channel halves, 72 VGPRs) are loaded once per workgroup straight from the [cout][kh][kw][cin]
+//      weights (16 contiguous bytes per lane); per output row 18 x (ds_read_b128, MFMA), bias + ReLU,
+//      half-wave exchange, 16-byte stores.
+#define S12_R2 4
+#define S12_C2 32
+#define S12_S1R (2 * S12_R2 + 1)            // 9 stem1 rows
+#define S12_S1C (2 * S12_C2 + 1)            // 65 stem1 columns
+#define S12_PR (2 * S12_S1R + 1)            // 19 patch rows
+#define S12_PE ((2 * S12_S1C + 1) * 3)      // 393 patch elements per row
+#define S12_PITCH 400                       // halfs per patch row
+#define S12_PATCH_HALFS (S12_PR * S12_PITCH + 16)    // the windows of the last column read up to 8 halfwords past a row
+#define S12_PIX 80                          // bytes per stem1 pixel in LDS (64 used)
+#define S12_S1BYTES (S12_S1R * 2 * 33 * S12_PIX)
+
+__global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
+    __shared__ __attribute__((aligned(16))) _Float16 patch[S12_PATCH_HALFS];
+    __shared__ __attribute__((aligned(16))) unsigned char s1[S12_S1BYTES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wo2 + S12_C2 - 1) / S12_C2;
+    const int tiles_y = (p.Ho2 + S12_R2 - 1) / S12_R2;
+    const int n_tiles = p.B * tiles_y * tiles_x;
+
+    // ---- per-workgroup constants: stem1 A fragments (k' = kw*3 + c, RGB order; see stem_u8_kernel),
+    // stem2 A fragments of this wave's cout group, biases
+    half8 wa[3];
+    {
+        const int co = r;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * h + j;
+                _Float16 w = (_Float16)0.f;
+                if (k < 9) {
+                    const int kw = k / 3, c = k - kw * 3;
+                    w = p.w1[((co * 3 + kh) * 3 + kw) * 8 + c];
+                }
+                wa[kh][j] = w;
+            }
+    }
+    const int g2 = wave & 1;
+    half8 wb[18];
+#pragma unroll
+    for (int m = 0; m < 18; ++m)
+        wb[m] = *reinterpret_cast<const half8*>(p.w2 + (((g2 * 32 + r) * 9 + (m >> 1)) * 32 + 16 * (m & 1) + 8 * h));
+    floatx4 b1[4], b2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        b1[g] = *reinterpret_cast<const floatx4*>(p.bias1 + 8 * g + 4 * h);
+        b2[g] = *reinterpret_cast<const floatx4*>(p.bias2 + 32 * g2 + 8 * g + 4 * h);
+    }
+    for (int e = t; e < S12_PATCH_HALFS - S12_PR * S12_PITCH; e += 256) patch[S12_PR * S12_PITCH + e] = (_Float16)0.f;
+
+    // The u8 patch of a tile is fetched as aligned dwords (99 per patch row, 8 per thread) one tile AHEAD:
+    // the loads are issued before phase B of the previous tile and unpacked in phase A, so their HBM
+    // latency hides under a whole tile of work (19 dependent row round trips per tile without this).
+    constexpr int DW_ROW = 99;                                  // dwords covering 393 bytes at any alignment
+    constexpr int DW_PER_THREAD = (S12_PR * DW_ROW + 255) / 256;   // 8
+    const uint8_t* const buf_lo = p.frames;
+    const uint8_t* const buf_hi = p.frames + (long)p.B * p.frame_stride;
+    unsigned pre[DW_PER_THREAD];
+    auto tile_coords = [&](int tile, int& b, int& y2_0, int& x2_0) {
+        int q = tile;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        b = q / tiles_y;
+        y2_0 = ty * S12_R2;
+        x2_0 = tx * S12_C2;
+    };
+    // byte address of patch row pr, element 0 (may lie outside the frame / the buffer: masked later)
+    auto row_addr = [&](int b, int y2_0, int x2_0, int pr) -> const uint8_t* {
+        int iy = 4 * y2_0 - 3 + pr;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        return p.frames + (long)b * p.frame_stride + (long)iy * p.row_stride + (long)(4 * x2_0 - 3) * 3;
+    };
+    auto prefetch = [&](int tile) {
+        int b, y2_0, x2_0;
+        tile_coords(tile, b, y2_0, x2_0);
+#pragma unroll
+        for (int i = 0; i < DW_PER_THREAD; ++i) {
+            const int idx = t + i * 256;
+            const int pr = idx / DW_ROW, d = idx - pr * DW_ROW;
+            unsigned v = 0u;
+            if (pr < S12_PR) {
+                const uint8_t* a = row_addr(b, y2_0, x2_0, pr);
+                const uint8_t* al = a - ((uintptr_t)a & 3) + 4 * d;        // aligned dword d of this row
+                if (al >= buf_lo && al + 4 <= buf_hi) {
+                    v = *reinterpret_cast<const unsigned*>(al);
+                } else {                                                    // first / last bytes of the whole batch
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (al + j >= buf_lo && al + j < buf_hi) v |= (unsigned)al[j] << (8 * j);
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int b, y2_0, x2_0;
+        tile_coords(tile, b, y2_0, x2_0);
+        const int s1r0 = 2 * y2_0 - 1, s1c0 = 2 * x2_0 - 1;      // stem1 coordinates of the tile's first row / column
+        const int iy0 = 2 * s1r0 - 1, ix0 = 2 * s1c0 - 1;        // input coordinates of the patch origin
+
+        // ---- A: unpack the prefetched dwords into the normalised fp16 patch (RGB order).  Tiles whose
+        // patch lies inside the frame (all but the border ring) skip the per-element padding logic.
+        const bool interior = iy0 >= 0 && iy0 + S12_PR <= p.H && ix0 >= 0 && ix0 + (2 * S12_S1C + 1) <= p.W;
+#pragma unroll
+        for (int i = 0; i < DW_PER_THREAD; ++i) {
+            const int idx = t + i * 256;
+            const int pr = idx / DW_ROW, d = idx - pr * DW_ROW;
+            if (pr < S12_PR) {
+                const int sh = (int)((uintptr_t)row_addr(b, y2_0, x2_0, pr) & 3);
+                const int e0 = 4 * d - sh;                            // patch-row element of byte 0 (-3 .. 392)
+                int px = (e0 + 3) / 3 - 1, c = e0 - px * 3;           // floor division for e0 >= -3
+                _Float16* prow = patch + pr * S12_PITCH;
+                const int iy = iy0 + pr;
+                const bool yin = (unsigned)iy < (unsigned)p.Hc;
+                const bool yimg = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j;
+                    if (e >= 0 && e < S12_PE) {
+                        float v = ((float)((pre[i] >> (8 * j)) & 0xffu) - 127.5f) * (1.0f / 128.0f);
+                        if (!interior) {
+                            const int ix = ix0 + px;
+                            const bool in_canvas = yin && (unsigned)ix < (unsigned)p.Wc;
+                            const bool in_frame = yimg && ix < p.W;
+                            // conv padding: 0 in the normalised domain; letterbox canvas: u8 zero
+                            v = in_canvas ? (in_frame ? v : (0.f - 127.5f) * (1.0f / 128.0f)) : 0.f;
+                        }
+                        prow[px * 3 + (p.rgb_in ? c : 2 - c)] = (_Float16)v;
+                    }
+                    if (++c == 3) { c = 0; ++px; }
+                }
+            }
+        }
+        for (int e = t; e < S12_PR * (S12_PITCH - S12_PE); e += 256) {   // row tails read by the last windows
+            const int pr = e / (S12_PITCH - S12_PE);
+            patch[pr * S12_PITCH + S12_PE + (e - pr * (S12_PITCH - S12_PE))] = (_Float16)0.f;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) prefetch(tile + gridDim.x);   // lands during phases B and C
+
+        // ---- B: stem1 on the halo'd tile -> LDS.  18 (row, 32-column group) jobs + one job whose 32
+        // "pixels" are column 64 of the 9 rows (lanes r >= 9 idle along), over 4 waves.
+        for (int job = wave; job < S12_S1R * 2 + 1; job += 4) {
+            const bool extra = job == S12_S1R * 2;
+            const int row = extra ? (r < S12_S1R ? r : 0) : job >> 1;
+            const int col = extra ? 2 * S12_C2 : (job & 1) * 32 + r;   // tile-local stem1 column of this lane's pixel
+            const unsigned* win = reinterpret_cast<const unsigned*>(patch + (2 * row) * S12_PITCH + 6 * col + 8 * h);
+            floatx16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                union { unsigned u[4]; half8 v; } bf;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) bf.u[qq] = win[kh * (S12_PITCH / 2) + qq];
+                acc = mfma16(wa[kh], bf.v, acc);
+            }
+            const int gy = s1r0 + row, gx = s1c0 + col;            // global stem1 coordinates
+            const bool inside = (unsigned)gy < (unsigned)p.Ho1 && (unsigned)gx < (unsigned)p.Wo1;
+            union { half4 v; unsigned u[2]; } pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pk[g].v[e] = inside ? (_Float16)fmaxf(acc[4 * g + e] + b1[g][e], 0.f) : (_Float16)0.f;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                swap_halves(pk[2 * qq].u[0], pk[2 * qq + 1].u[0]);
+                swap_halves(pk[2 * qq].u[1], pk[2 * qq + 1].u[1]);
+            }
+            // after the exchange lane (pixel r, half h) holds couts 16*qq + 8*h .. +7 of its pixel.  But the
+            // exchange pairs lane l with l+32: `inside` of both lanes is the same pixel, so the zeros agree.
+            if (!extra || r < S12_S1R) {
+                unsigned char* dst = s1 + ((row * 2 + (col & 1)) * 33 + (col >> 1)) * S12_PIX;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                    *reinterpret_cast<uint4*>(dst + (2 * qq + h) * 16) =
+                        make_uint4(pk[2 * qq].u[0], pk[2 * qq].u[1], pk[2 * qq + 1].u[0], pk[2 * qq + 1].u[1]);
+            }
+        }
+        __syncthreads();
+
+        // ---- C: stem2 for this wave's cout group and two output rows
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            const int y = 2 * (wave >> 1) + yy;                    // tile-local output row
+            floatx16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 18; ++m) {
+                const int tap = m >> 1, kh = tap / 3, kw = tap - kh * 3;
+                const unsigned char* src = s1 + (((2 * y + kh) * 2 + (kw & 1)) * 33 + r + (kw >> 1)) * S12_PIX + (2 * (m & 1) + h) * 16;
+                acc = mfma16(wb[m], *reinterpret_cast<const half8*>(src), acc);
+            }
+            const int oy = y2_0 + y, ox = x2_0 + r;
+            union { half4 v; unsigned u[2]; } pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[g].v[e] = (_Float16)fmaxf(acc[4 * g + e] + b2[g][e], 0.f);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                swap_halves(pk[2 * qq].u[0], pk[2 * qq + 1].u[0]);
+                swap_halves(pk[2 * qq].u[1], pk[2 * qq + 1].u[1]);
+            }
+            if (oy < p.Ho2 && ox < p.Wo2) {
+                _Float16* o = p.out + (((long)b * p.Ho2 + oy) * p.Wo2 + ox) * 64 + 32 * g2;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                    *reinterpret_cast<uint4*>(o + 16 * qq + 8 * h) =
+                        make_uint4(pk[2 * qq].u[0], pk[2 * qq].u[1], pk[2 * qq + 1].u[0], pk[2 * qq + 1].u[1]);
+            }
+        }
+        // (no barrier here: the next tile's phase A only writes `patch`, which phase C does not read, and
+        // its barrier orders this phase C before the next phase B overwrites `s1`)
+    }
+}
+
+hipError_t launch_stem12_u8(const Stem12Params& p, hipStream_t stream) {
+    if (!p.frames || !p.w1 || !p.bias1 || !p.w2 || !p.bias2 || !p.out || p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Hc < p.H ||
+        p.Wc < p.W || (p.Hc & 3) || (p.Wc & 3) || p.Ho1 != p.Hc / 2 || p.Wo1 != p.Wc / 2 || p.Ho2 != p.Ho1 / 2 || p.Wo2 != p.Wo1 / 2)
+        return hipErrorInvalidValue;
+    const long tiles = (long)p.B * ((p.Ho2 + S12_R2 - 1) / S12_R2) * ((p.Wo2 + S12_C2 - 1) / S12_C2);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return hipErrorInvalidValue;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    int ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        ncu = prop.multiProcessorCount;
+    const long slots = 2L * ncu;                      // persistent: two workgroups per CU (63 KiB LDS each)
+    hipLaunchKernelGGL(stem12_u8_kernel, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_stem_u8(const StemParams& p, hipStream_t stream) {
     if (!p.frames || !p.w || !p.bias || !p.out || p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Hc < p.H || p.Wc < p.W ||
         (p.Hc & 1) || (p.Wc & 1) || p.Ho != p.Hc / 2 || p.Wo != p.Wc / 2)

@@ -243,20 +243,48 @@ def test_embed_parity_small_and_r100(engine):
         assert cos.min() > 1 - 1e-3, (blocks, cos)          # north_star tolerance
 
 
-def test_detector_head_maps_parity(engine):
-    rng = np.random.default_rng(21)
+@pytest.mark.parametrize("stem_env", [None, "FRP_NO_FUSED_STEM12", "FRP_NO_FUSED_STEM"])
+@pytest.mark.parametrize("shape", [(2, 150, 200), (1, 97, 131), (3, 64, 64)])
+def test_detector_head_maps_parity(engine, stem_env, shape, monkeypatch):
+    """all three stem paths (u8 -> stem1 -> stem2 in one kernel; fused stem1 + generic stem2; preprocess +
+    generic convs) against the fp32 oracle, on letterboxed canvases whose stem tiles are ragged"""
+    if stem_env:
+        monkeypatch.setenv(stem_env, "1")
+    B, H, W = shape
+    canvas = ((H + 31) // 32 * 32, (W + 31) // 32 * 32)
+    rng = np.random.default_rng(21 + H)
     raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
     engine.load_weights(blob)
-    frames = rng.integers(0, 256, size=(2, 150, 200, 3), dtype=np.uint8)   # canvas 160 x 224 (letterboxed)
+    frames = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
     engine.detect(frames, max_faces=4, det_thresh=0.5)
     heads = engine.head_maps()
-    ref = onet.det_forward(raw, onet.det_blob(frames, (160, 224)))
+    ref = onet.det_forward(raw, onet.det_blob(frames, canvas))
     for g, r in zip(heads, ref):
         assert g.shape[:3] == r.shape[:3]
         scale = max(1.0, float(np.abs(r).max()))
         err = np.abs(g[..., :30].astype(np.float32) - r).max()
         assert err < 2e-2 * scale, (err, scale)
         assert np.all(g[..., 30:] == 0)
+
+
+def test_fused_stems_agree_with_the_two_kernel_path(engine, monkeypatch):
+    """stem12_u8_kernel vs stem_u8_kernel + generic conv: same fp16 stem1 values, fp32 accumulation in a
+    different order -> head maps equal up to fp16 rounding noise; BGR and RGB inputs give the same result"""
+    rng = np.random.default_rng(5)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    frames = rng.integers(0, 256, size=(2, 200, 328, 3), dtype=np.uint8)
+    engine.detect(frames, max_faces=4, det_thresh=0.5)
+    a = [h.astype(np.float32) for h in engine.head_maps()]
+    engine.detect(frames[..., ::-1].copy(), max_faces=4, det_thresh=0.5, flags=2)       # FLAG_RGB
+    a_rgb = [h.astype(np.float32) for h in engine.head_maps()]
+    monkeypatch.setenv("FRP_NO_FUSED_STEM12", "1")
+    engine.detect(frames, max_faces=4, det_thresh=0.5)
+    b = [h.astype(np.float32) for h in engine.head_maps()]
+    for x, xr, y in zip(a, a_rgb, b):
+        assert np.array_equal(x, xr)
+        scale = max(1.0, float(np.abs(y).max()))
+        assert np.abs(x - y).max() < 4e-3 * scale
 
 
 @pytest.mark.parametrize("N,M,k", [(1000, 5, 7), (4097, 3, 64), (5, 2, 8), (100000, 4, 10)])
