@@ -26,9 +26,9 @@ HBM_PEAK_GBS = 8000.0
 
 def pmc_conv_traffic_per_launch(launches_per_step):
     """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r1/pmc_traffic_v4.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
+    command (profiles/r1/pmc_traffic_v5.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
     in separate passes as the microarch guide prescribes).  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v4.json")
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v5.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -204,7 +204,7 @@ def main():
                        "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in
                                              ("ms_preprocess", "ms_det_conv", "ms_decode", "ms_align", "ms_emb_conv",
                                               "ms_l2norm", "ms_match")}},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_rows_kernel + conv_mfma_kernel (implicit-GEMM conv family, all detector+embedder launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_rows_kernel + conv_mfma_kernel + stem12_u8_kernel (implicit-GEMM conv family, all detector+embedder launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_conv_traffic_per_launch(launches // max(1, args.steps)),
