@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--pcie-steps", type=int, default=6, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     args = ap.parse_args()
 
     # Everything except the final JSON line goes to stderr: RCCL prints a version banner on the
@@ -181,6 +182,32 @@ def main():
     res = eng.fetch_results()
     assert np.all(res["counts"] == K)
 
+    # PCIe-inclusive rate (never `value`): the same batch handed over as HOST frames every step.  Two page-locked
+    # staging buffers; the copy of step t+1 runs on the library's copy stream while step t is processed.
+    pcie = None
+    if args.pcie_steps > 0 and rank == 0:
+        stage = [eng.host_frames(B, H, W) for _ in range(2)]
+        for s_ in stage:
+            s_[...] = frames
+        eng.upload_frames_async(stage[0])
+        eng.swap_frames()
+        eng.upload_frames_async(stage[1])
+        eng.process_resident(K, flags=flags)             # warm-up of the overlapped loop
+        eng.fetch_results()
+        eng.swap_frames()
+        t1 = time.perf_counter()
+        for i in range(args.pcie_steps):
+            eng.upload_frames_async(stage[i & 1])
+            eng.process_resident(K, flags=flags)
+            r2 = eng.fetch_results()                     # host results of every step
+            eng.swap_frames()
+        eng.synchronize()
+        dt2 = time.perf_counter() - t1
+        assert np.all(r2["counts"] == K)
+        pcie = {"faces_per_s": round(args.pcie_steps * B * K / dt2, 1), "ms_per_step": round(dt2 / args.pcie_steps * 1e3, 3),
+                "steps": args.pcie_steps,
+                "mode": "host u8 frames in (page-locked, H2D on a copy stream overlapped with the previous step), host results out every step"}
+
     if rank == 0:
         faces_total = world * args.steps * B * K
         conv_ms = ctr["ms_det_conv"] + ctr["ms_emb_conv"]
@@ -199,6 +226,7 @@ def main():
                                    f"{N}-identity fp16 gallery, FRPDet detector + ArcFace IResNet-100 fp16 (synthetic seeded weights)",
                        "frames_per_s": round(world * args.steps * B / dt, 2),
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
+                       "pcie_inclusive": pcie,
                        "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
                        "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),
                        "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in

@@ -56,6 +56,13 @@ struct frp_handle {
     // resident frames (tightly packed u8 [B,H,W,3])
     DevBuf frames;
     int rB = 0, rH = 0, rW = 0;
+    // overlapped ingest: the NEXT batch is copied on its own stream while the current one is processed
+    DevBuf frames_next;
+    int nB = 0, nH = 0, nW = 0;
+    bool next_valid = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_next_ready = nullptr, ev_next_free = nullptr;
+    std::vector<void*> pinned;       // frp_host_alloc blocks, freed with the handle
     // detector source: the resident frames, or a resized copy of them (pyramid scales)
     DevBuf scaled;
     int dH = 0, dW = 0;              // dims of the detector source
@@ -630,6 +637,9 @@ int frp_create(int device, const frp_config* cfg, frp_handle** out) {
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->h_nfaces, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_next_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_next_free, hipEventDisableTiming) == hipSuccess;
     if (!ok) { frp_destroy(h); return FRP_ERR_HIP; }
     h->ctr.struct_size = sizeof(frp_counters);
     *out = h;
@@ -640,13 +650,18 @@ void frp_destroy(frp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
-    DevBuf* all[] = {&h->wdata, &h->frames, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
+    DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
                      &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
+    for (void* p : h->pinned) (void)hipHostFree(p);
+    if (h->ev_next_ready) (void)hipEventDestroy(h->ev_next_ready);
+    if (h->ev_next_free) (void)hipEventDestroy(h->ev_next_free);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -772,6 +787,67 @@ int frp_upload_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, i
     Guard g(h);
     FRPCHK(upload_frames(h, bgr, B, H, W, row_stride));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+void* frp_host_alloc(frp_handle* h, size_t bytes) {
+    if (!h || bytes == 0) return nullptr;
+    Guard g(h);
+    void* p = nullptr;
+    if (hipSetDevice(h->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(h, FRP_ERR_OOM, "hipHostMalloc failed");
+        return nullptr;
+    }
+    h->pinned.push_back(p);
+    return p;
+}
+
+void frp_host_free(frp_handle* h, void* p) {
+    if (!h || !p) return;
+    Guard g(h);
+    for (size_t i = 0; i < h->pinned.size(); ++i)
+        if (h->pinned[i] == p) {
+            (void)hipStreamSynchronize(h->copy_stream);
+            (void)hipHostFree(p);
+            h->pinned.erase(h->pinned.begin() + (long)i);
+            return;
+        }
+}
+
+int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!bgr || B <= 0 || H <= 0 || W <= 0 || row_stride < (int64_t)W * 3) return fail(h, FRP_ERR_INVALID, "bad frame arguments");
+    if (B > 1024) return fail(h, FRP_ERR_INVALID, "batch too large (max 1024 frames per call)");
+    const size_t need = (size_t)B * H * W * 3;
+    if (need > h->frames_next.cap || !h->frames_next.p) {
+        // growing the staging buffer: nothing may still be copying into / computing from it
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        FRPCHK(ensure(h, h->frames_next, need));
+    }
+    // the staging buffer was the resident one until the last swap: wait for the work enqueued before it
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_next_free, 0));
+    HIPCHK(h, hipMemcpy2DAsync(h->frames_next.p, (size_t)W * 3, bgr, (size_t)row_stride, (size_t)W * 3, (size_t)B * H,
+                               hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_next_ready, h->copy_stream));
+    h->nB = B; h->nH = H; h->nW = W;
+    h->next_valid = true;
+    return FRP_OK;
+}
+
+int frp_swap_frames(frp_handle* h) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->next_valid) return fail(h, FRP_ERR_INVALID, "no staged frames (call frp_upload_frames_async)");
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_next_ready, 0));     // compute waits for the staged copy
+    std::swap(h->frames, h->frames_next);
+    HIPCHK(h, hipEventRecord(h->ev_next_free, h->stream));            // ... and the old resident buffer is free after
+    h->rB = h->nB; h->rH = h->nH; h->rW = h->nW;                       // everything enqueued so far
+    h->dH = h->rH; h->dW = h->rW; h->det_scaled = false;
+    h->canvas_h = round_up(h->rH, 32);
+    h->canvas_w = round_up(h->rW, 32);
+    h->next_valid = false;
     return FRP_OK;
 }
 

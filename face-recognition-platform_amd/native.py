@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_update_row", "frp_gallery_remove_row",
     "frp_gallery_size", "frp_gallery_get",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
+    "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
     "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_get_counters", "frp_reset_counters",
 ]
@@ -84,6 +85,12 @@ def load_library() -> C.CDLL:
     lib.frp_process_resident.argtypes = [vp, i32, f32, f32, u32]
     lib.frp_fetch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.frp_synchronize.argtypes = [vp]
+    lib.frp_host_alloc.argtypes = [vp, C.c_size_t]
+    lib.frp_host_alloc.restype = vp
+    lib.frp_host_free.argtypes = [vp, vp]
+    lib.frp_host_free.restype = None
+    lib.frp_upload_frames_async.argtypes = [vp, vp, i32, i32, i32, i64]
+    lib.frp_swap_frames.argtypes = [vp]
     lib.frp_detect.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_detect_resident.argtypes = [vp, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_get_det_source.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
@@ -206,6 +213,26 @@ class Engine:
         frames, B, H, W, rs = self._frames(frames)
         self._chk(self._lib.frp_upload_frames(self._h, _ptr(frames), B, H, W, rs))
         self._resident = (B, H, W)
+
+    def host_frames(self, B: int, H: int, W: int) -> np.ndarray:
+        """page-locked u8 [B,H,W,3] array owned by the engine (freed with it): frames written here can be
+        copied to the device while the previous batch is being processed"""
+        n = B * H * W * 3
+        p = self._lib.frp_host_alloc(self._h, n)
+        if not p:
+            raise FrpError(self._lib.frp_last_error(self._h).decode())
+        buf = (C.c_uint8 * n).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(B, H, W, 3)
+
+    def upload_frames_async(self, frames: np.ndarray):
+        """stage the NEXT batch (copy stream); becomes resident at swap_frames()"""
+        frames, B, H, W, rs = self._frames(frames)
+        self._chk(self._lib.frp_upload_frames_async(self._h, _ptr(frames), B, H, W, rs))
+        self._staged = (B, H, W)
+
+    def swap_frames(self):
+        self._chk(self._lib.frp_swap_frames(self._h))
+        self._resident = self._staged
 
     def process_resident(self, max_faces: int = 10, det_thresh: float = 0.5, nms_iou: float = 0.4, flags: int = 0):
         self._chk(self._lib.frp_process_resident(self._h, max_faces, det_thresh, nms_iou, flags))

@@ -135,6 +135,17 @@ int frp_fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, in
                       float* emb, int32_t* match_idx, float* match_cos);
 int frp_synchronize(frp_handle* h);
 
+/* Overlapped ingest for streaming callers (the camera loop keeps producing frames while the previous
+ * batch is on the GPU, camera.py:277-305): the NEXT batch is copied host -> device on a private copy
+ * stream into a staging buffer while the resident batch is being processed; frp_swap_frames makes the
+ * staged batch the resident one (stream-ordered, no host wait).  The copy only overlaps when `bgr` is
+ * page-locked: frp_host_alloc hands out such memory (freed by frp_host_free or with the handle).
+ *     upload_async(t+1); process_resident(t); fetch_results(t); swap_frames(); ...                  */
+void* frp_host_alloc(frp_handle* h, size_t bytes);
+void frp_host_free(frp_handle* h, void* p);
+int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride);
+int frp_swap_frames(frp_handle* h);
+
 /* ---- stage entry points (REST paths and parity tests) ------------------------------- */
 /* detection only -> face_recognition.face_locations (camera.py:232) */
 int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,

@@ -100,6 +100,42 @@ def test_forced_k_and_resident_path(engine):
     assert np.array_equal(a["emb"], d["emb"])
 
 
+def test_overlapped_ingest_equals_plain_calls(engine):
+    """upload_async(t+1) | process(t) | fetch(t) | swap: every batch gives exactly the results of a plain
+    process_frames call, also when the batch shape changes and when the staged copy is still running
+    at swap time (pinned source) or was a blocking copy (pageable source)."""
+    rng = np.random.default_rng(99)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    engine.gallery_set(rng.standard_normal((200, 512)).astype(np.float32))
+    K = 3
+    shapes = [(4, 128, 160), (4, 128, 160), (2, 96, 224), (4, 128, 160), (1, 160, 128)]
+    batches = [_frames(rng, *s) for s in shapes]
+    want = [engine.process_frames(f, max_faces=K, flags=1) for f in batches]
+    pinned = {}
+    def staged(i):
+        f = batches[i]
+        if i % 2 == 0:                                   # even batches go through page-locked memory
+            buf = pinned.setdefault(f.shape, engine.host_frames(*f.shape[:3]))
+            buf[...] = f
+            return buf
+        return f
+    engine.upload_frames_async(staged(0))
+    engine.swap_frames()
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            engine.upload_frames_async(staged(i + 1))    # overlaps the processing of batch i
+        engine.process_resident(max_faces=K, flags=1)
+        got = engine.fetch_results()
+        for key in ("boxes", "kps", "scores", "counts", "emb", "match_idx", "match_cos"):
+            assert np.array_equal(got[key], want[i][key]), (i, key)
+        if i + 1 < len(batches):
+            engine.swap_frames()
+    from frp_amd.native import FrpError
+    with pytest.raises(FrpError):
+        engine.swap_frames()                              # nothing staged
+
+
 def test_no_faces_and_no_gallery(engine):
     raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
     engine.load_weights(blob)
