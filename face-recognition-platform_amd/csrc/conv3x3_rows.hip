@@ -242,12 +242,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             }
             obase[i] = (long)m * p.Cout;
             if (has_res) {
+                // 16-byte loads in the STORE layout (couts 16q + 8*fh .. +7 of this pixel), then the same half-wave
+                // exchange as for the stores (it is its own inverse) back into the accumulator layout: half as many,
+                // twice as wide loads as reading the 4-cout accumulator runs directly
 #pragma unroll
                 for (int j = 0; j < MC; ++j)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                        r4[i][j][g] = *reinterpret_cast<const half4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
+                    for (int q = 0; q < 2; ++q) {
+                        const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                        uint4 rr = *reinterpret_cast<const uint4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
+                        swap_halves(rr.x, rr.z);
+                        swap_halves(rr.y, rr.w);
+                        union { unsigned u[2]; half4 h; } lo, hi;
+                        lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
+                        r4[i][j][2 * q] = lo.h;
+                        r4[i][j][2 * q + 1] = hi.h;
                     }
             }
         }

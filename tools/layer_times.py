@@ -31,11 +31,12 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     frames, faces = 32, 320
-    starts = [i for i, r in enumerate(rows) if "stem_u8" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "stem_u8" in r["Kernel_Name"] or "stem12_u8" in r["Kernel_Name"]]
     seq = rows[starts[-1]:]
+    fused2 = "stem12_u8" in seq[0]["Kernel_Name"]
     det = walk(ns.detector_layers(), 1088, 1920, "det.in", frames)
     emb = walk(ns.iresnet_layers(), 112, 112, "emb.in", faces)
-    convs = iter(det[1:] + emb)
+    convs = iter(det[2 if fused2 else 1:] + emb)
     prev_end, t0, tot, tot_gap = None, int(seq[0]["Start_Timestamp"]), 0.0, 0.0
     for r in seq:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
