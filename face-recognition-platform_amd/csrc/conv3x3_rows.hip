@@ -220,6 +220,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     // ---------------- epilogue of tile ct (as in conv_mfma.hip): bias / border-class bias from the
     // LDS parameter cache, residual, activation in fp32, 16-byte fp16 stores after a half-wave
     // exchange; interior tiles take the unpredicated copy.
+    // The residual of a tile is requested one k-step EARLY (at the start of the tile's last k-step, right
+    // after that step's counted wait, so the loads sit behind nothing the ring waits for): on the big
+    // detector maps it comes from HBM, and an epilogue that issued the loads itself sat out their latency.
+    uint4 rres[MP][MC][2];
+    auto issue_residual_loads = [&](int m0, int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int mraw = m0 + prow0 + i * 32 + fr;
+            const int m = mraw < p.M ? mraw : 0;
+            long ridx = (long)m * p.Cout;
+            if (up2) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // 16-byte loads in the STORE layout (couts 16q + 8*fh .. +7 of this pixel); clamped, always valid
+                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                    rres[i][j][q] = *reinterpret_cast<const uint4*>(p.res + ridx + (co < p.Cout ? co : 0));
+                }
+        }
+    };
+
     auto epilogue_body = [&](auto FULL_T, int m0, int c0) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(FULL_T)::value;
         half4 r4[MP][MC][4];
@@ -231,26 +258,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             const int mraw = m0 + prow0 + i * 32 + fr;
             mok[i] = FULL || mraw < p.M;
             const int m = mok[i] ? mraw : 0;
-            long ridx = (long)m * p.Cout;
             cls[i] = 0;
-            if (border || up2) {
+            if (border) {
                 int n, rem, oy, ox;
                 fast_divmod(m, HoWo, inv_howo, n, rem);
                 fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                if (border) cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-                if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+                cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
             }
             obase[i] = (long)m * p.Cout;
             if (has_res) {
-                // 16-byte loads in the STORE layout (couts 16q + 8*fh .. +7 of this pixel), then the same half-wave
-                // exchange as for the stores (it is its own inverse) back into the accumulator layout: half as many,
-                // twice as wide loads as reading the 4-cout accumulator runs directly
+                // the same half-wave exchange as for the stores (it is its own inverse) turns the 16-byte
+                // store-layout chunks into the accumulator layout
 #pragma unroll
                 for (int j = 0; j < MC; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
-                        uint4 rr = *reinterpret_cast<const uint4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
+                        uint4 rr = rres[i][j][q];
                         swap_halves(rr.x, rr.z);
                         swap_halves(rr.y, rr.w);
                         union { unsigned u[2]; half4 h; } lo, hi;
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         // One k-step: wait for this wave's share of the stage, barrier (every wave's share landed;
         // every wave is done with the slots the next issues overwrite), 4 x (fragment reads, MFMA
         // group) with this step's DMA pieces fired in between.
-#define ROWS_STEP(KW, FIRST)                                                                          \
+#define ROWS_STEP(KW, FIRST, LASTSTEP)                                                                          \
     do {                                                                                              \
         if (last_cnt == WI + 2) wait_vmcnt<WI + 2>();                                                 \
         else if (last_cnt == WI + 1) wait_vmcnt<WI + 1>();                                            \
@@ -359,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                \
             bbase[i] = ((tapmask[i] >> (kh * 3 + (KW))) & 1u) ? xsoff + brow[KW][i] : OFF_Z + (brow[KW][i] & 128); \
         if (FIRST) fetch_params(ct);                                                                  \
+        if ((LASTSTEP) && has_res) issue_residual_loads(m0, c0);                                      \
         read_frags(wsoff, KW, 0, 0);                                                                  \
         int cnt = 0;                                                                                  \
         /* weight pieces first: their slack is two k-steps at best, the row patches have six */      \
@@ -384,10 +408,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
                 // right after an epilogue its stores are pending too (vmcnt counts them, in issue
                 // order, behind the DMAs): drain everything there
                 if (first && ct != t0) last_cnt = -1;
-                ROWS_STEP(0, first);
+                ROWS_STEP(0, first, false);
                 if (first && ct == t0) stamp(p.stamps, 3);
-                ROWS_STEP(1, false);
-                ROWS_STEP(2, false);
+                ROWS_STEP(1, false, false);
+                ROWS_STEP(2, false, cb == cpt - 1 && kh == 2);
             }
         }
 #undef ROWS_STEP

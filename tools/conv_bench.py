@@ -24,6 +24,9 @@ SHAPES = [
     ("det.stem1 8->32 s2 1088x1920", 32, 1088, 1920, 8, 32, 3, 2, 1, 0, False, 1),
     ("det.stem2 32->64 s2 544x960", 32, 544, 960, 32, 64, 3, 2, 1, 0, False, 1),
     ("det.head out 128->32",      32, 136, 240, 128, 32, 3, 1, 0, 0, False, 1),
+    ("det 128->128 +res 136x240",  32, 136, 240, 128, 128, 3, 1, 1, 0, True, 1),
+    ("det 64->64 +res 272x480",    32, 272, 480, 64, 64, 3, 1, 1, 0, True, 1),
+    ("det 256->256 +res 68x120",   32, 68, 120, 256, 256, 3, 1, 1, 0, True, 1),
     # generic-kernel shapes (stride 2, 1x1)
     ("det 64->128 s2 272x480",    32, 272, 480, 64, 128, 3, 2, 1, 0, False, 1),
     ("det 128->256 s2 136x240",   32, 136, 240, 128, 256, 3, 2, 1, 0, False, 1),
