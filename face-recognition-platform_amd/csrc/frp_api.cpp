@@ -221,6 +221,27 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         skip = 2;
         first = false;
     }
+    // embedder stem (chips NHWC8 -> 3x3 s1 3->64 + PReLU): dedicated kernel; FRP_NO_EMB_STEM=1 keeps the generic one
+    if (!stem && !net.ops.empty()) {
+        const frp_conv_op& a = net.ops[0];
+        if (a.in_buf == net.in_buf && a.cin == 8 && (a.real_ch & 0xffff) == 3 && a.cout == 64 && a.ksize == 3 && a.stride == 1 &&
+            a.act == FRP_ACT_PRELU && a.res_buf < 0 && a.flags == 0 && a.slope_off >= 0 && !getenv("FRP_NO_EMB_STEM")) {
+            EmbStemParams ep{};
+            ep.x = (const _Float16*)net.bufs[a.in_buf].p;
+            ep.M = batch; ep.H = H; ep.W = W;
+            ep.w = (const _Float16*)(wbase + a.w_off);
+            ep.bias = (const float*)(wbase + a.bias_off);
+            ep.slope = (const float*)(wbase + a.slope_off);
+            ep.out = (_Float16*)net.bufs[a.out_buf].p;
+            hipError_t e = launch_emb_stem(ep, h->stream);
+            if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_emb_stem: ") + hipGetErrorString(e));
+            d[a.out_buf] = {H, W, 64, false};
+            *flops += 2.0 * batch * H * W * 9.0 * 3 * 64;
+            *launches += 1;
+            skip = 1;
+            first = false;
+        }
+    }
     for (const frp_conv_op& op : net.ops) {
         if (skip) { --skip; continue; }
         if (first && stem) {

@@ -76,6 +76,17 @@ struct Stem12Params {
 };
 hipError_t launch_stem12_u8(const Stem12Params& p, hipStream_t stream);
 
+// embedder stem: chips fp16 NHWC8 (3 real channels) -> conv3x3 s1 (3 -> 64) + bias + PReLU, fp16 NHWC64
+struct EmbStemParams {
+    const _Float16* x;       // [M,H,W,8]
+    int M, H, W;
+    const _Float16* w;       // folded [64][3][3][8] fp16 (channels R,G,B,0..)
+    const float* bias;       // [64]
+    const float* slope;      // [64]
+    _Float16* out;           // [M,H,W,64]
+};
+hipError_t launch_emb_stem(const EmbStemParams& p, hipStream_t stream);
+
 // K3: decode + candidate select + sort + NMS, one workgroup per frame
 struct DecodeParams {
     const _Float16* head[3];   // per stride [B, H_l, W_l, 32]

@@ -401,6 +401,117 @@ hipError_t launch_stem12_u8(const Stem12Params& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Embedder stem: aligned chips (fp16 NHWC8, 3 real channels) -> conv3x3 s1 (3 -> 64) + bias + PReLU,
+// fp16 NHWC64.  The generic kernel pads K = 27 to 128 and gathers per lane; this layer is bound by its
+// 514 MB output (320 faces), so it gets the stem treatment: per kernel row the three taps of a pixel are
+// 12 consecutive halfwords of an RGB0-packed LDS patch (k' = kw*4 + c), one MFMA (K = 16) per kernel
+// row and cout group, B fragments shared by both cout groups.
+// One workgroup = 8 output rows x up to 128 columns of one image (4 waves, 2 rows each).
+#define ES_ROWS 8
+#define ES_COLS 128
+#define ES_PITCH 132        // patch pixels per row: columns -1 .. 130 (the upper half-wave reads two pixels further)
+
+__global__ __launch_bounds__(256) void emb_stem_kernel(EmbStemParams p) {
+    __shared__ __attribute__((aligned(16))) uint2 patch[(ES_ROWS + 2) * ES_PITCH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + ES_COLS - 1) / ES_COLS;
+    const int tiles_y = (p.H + ES_ROWS - 1) / ES_ROWS;
+    int q = blockIdx.x;
+    const int tx = q % tiles_x; q /= tiles_x;
+    const int ty = q % tiles_y;
+    const int img = q / tiles_y;
+    const int y0 = ty * ES_ROWS, x0 = tx * ES_COLS;
+    const _Float16* chip = p.x + (long)img * p.H * p.W * 8;
+
+    // ---- patch: rows y0-1 .. y0+8, columns x0-1 .. x0+130; first 8 bytes (R,G,B,0) of each NHWC8 pixel
+    for (int e = t; e < (ES_ROWS + 2) * ES_PITCH; e += 256) {
+        const int pr = e / ES_PITCH, pc = e - pr * ES_PITCH;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        uint2 v = make_uint2(0u, 0u);
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+            v = *reinterpret_cast<const uint2*>(chip + ((long)y * p.W + x) * 8);
+        patch[e] = v;
+    }
+    // ---- weights: A fragments [cout group][kernel row]; lane (cout r, half h): k' = 8h + j = kw*4 + c
+    half8 wa[2][3];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const _Float16* w = p.w + (((cg * 32 + r) * 3 + kh) * 3) * 8;        // [kw][8]
+            union { uint2 u[2]; half8 v; } f;
+            f.u[0] = *reinterpret_cast<const uint2*>(w + (2 * h) * 8);            // kw = 0 (h=0) / 2 (h=1), channels 0..3
+            f.u[1] = h ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2*>(w + 8);   // kw = 1 / none
+            wa[cg][kh] = f.v;
+        }
+    floatx4 bias[2][4], slope[2][4];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias[cg][g] = *reinterpret_cast<const floatx4*>(p.bias + 32 * cg + 8 * g + 4 * h);
+            slope[cg][g] = *reinterpret_cast<const floatx4*>(p.slope + 32 * cg + 8 * g + 4 * h);
+        }
+    __syncthreads();
+
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy) {
+        const int yl = 2 * wave + yy, oy = y0 + yl;
+#pragma unroll
+        for (int cgp = 0; cgp < ES_COLS / 32; ++cgp) {
+            const int xl = cgp * 32 + r, ox = x0 + xl;
+            if (x0 + cgp * 32 >= p.W) break;                                       // uniform: no column of this group exists
+            floatx16 acc[2];
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cg][e] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const uint2* src = patch + (yl + kh) * ES_PITCH + xl + 2 * h;      // taps start at column ox-1 = patch column xl
+                union { uint2 u[2]; half8 v; } bf;
+                bf.u[0] = src[0];
+                bf.u[1] = src[1];
+                acc[0] = mfma16(wa[0][kh], bf.v, acc[0]);
+                acc[1] = mfma16(wa[1][kh], bf.v, acc[1]);
+            }
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                union { half4 v; unsigned u[2]; } pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[cg][4 * g + e] + bias[cg][g][e];
+                        pk[g].v[e] = (_Float16)(v > 0.f ? v : v * slope[cg][g][e]);
+                    }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    swap_halves(pk[2 * qq].u[0], pk[2 * qq + 1].u[0]);
+                    swap_halves(pk[2 * qq].u[1], pk[2 * qq + 1].u[1]);
+                }
+                if (oy < p.H && ox < p.W) {
+                    _Float16* o = p.out + (((long)img * p.H + oy) * p.W + ox) * 64 + 32 * cg;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+                        *reinterpret_cast<uint4*>(o + 16 * qq + 8 * h) =
+                            make_uint4(pk[2 * qq].u[0], pk[2 * qq].u[1], pk[2 * qq + 1].u[0], pk[2 * qq + 1].u[1]);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_emb_stem(const EmbStemParams& p, hipStream_t stream) {
+    if (!p.x || !p.w || !p.bias || !p.slope || !p.out || p.M <= 0 || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
+    const long tiles = (long)p.M * ((p.H + ES_ROWS - 1) / ES_ROWS) * ((p.W + ES_COLS - 1) / ES_COLS);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(emb_stem_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_stem_u8(const StemParams& p, hipStream_t stream) {
     if (!p.frames || !p.w || !p.bias || !p.out || p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Hc < p.H || p.Wc < p.W ||
         (p.Hc & 1) || (p.Wc & 1) || p.Ho != p.Hc / 2 || p.Wo != p.Wc / 2)

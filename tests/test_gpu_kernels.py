@@ -230,6 +230,21 @@ def test_align_parity(engine):
     assert err.mean() < 5e-4
 
 
+def test_embedder_stem_kernel_agrees_with_generic_conv(engine, monkeypatch):
+    """emb_stem_kernel vs the generic small-Cin conv path on the same chips: same fp16 inputs, fp32
+    accumulation in a different order -> embeddings equal to ~1e-4"""
+    rng = np.random.default_rng(19)
+    chips = rng.integers(0, 256, size=(5, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    a = engine.embed_aligned(chips)
+    monkeypatch.setenv("FRP_NO_EMB_STEM", "1")
+    b = engine.embed_aligned(chips)
+    assert np.abs(a - b).max() < 2e-3 and (a * b).sum(1).min() > 1 - 1e-5
+    ref = onet.emb_forward(raw, onet.emb_blob(chips))
+    assert (a * ref).sum(1).min() > 1 - 1e-3 and (b * ref).sum(1).min() > 1 - 1e-3
+
+
 def test_embed_parity_small_and_r100(engine):
     rng = np.random.default_rng(9)
     chips = rng.integers(0, 256, size=(3, 112, 112, 3), dtype=np.uint8)
