@@ -129,6 +129,37 @@ void release(DevBuf& b) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// OCP FP8 E4M3FN (bias 7, no infinities; S.1111.111 = NaN, decoded as 0 here: the packer never emits it)
+float fp8_e4m3_value(unsigned char c) {
+    const int e = (c >> 3) & 0xF, m = c & 7;
+    float v;
+    if (e == 15 && m == 7) v = 0.f;
+    else if (e == 0) v = std::ldexp((float)m / 8.0f, -6);
+    else v = std::ldexp(1.0f + (float)m / 8.0f, e - 7);
+    return (c & 0x80) ? -v : v;
+}
+
+// fp32 -> fp16 bit pattern, round to nearest even (the rounding of numpy's astype(float16))
+uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));     // NaN / inf
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                    // rounds to inf (>= 65520)
+    if (x < 0x33000001u) return (uint16_t)sign;                                                 // rounds to zero (<= 2^-25)
+    const int exp = (int)(x >> 23) - 127;
+    uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (exp < -14) { shift = 13 + (-14 - exp); base = 0; }                                      // subnormal half
+    else { shift = 13; base = (uint32_t)(exp + 15) << 10; mant &= 0x7fffffu; }
+    uint32_t q = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;                                            // a carry walks into the exponent
+    return (uint16_t)(sign | (base + q));
+}
+
 float logit_threshold(float t) {
     if (!(t > 0.f)) return -INFINITY;
     if (t >= 1.f) return INFINITY;
@@ -327,7 +358,9 @@ int parse_net(frp_handle* h, const unsigned char* blob, size_t bytes, uint64_t o
         if (!(op.ksize == 1 || op.ksize == 3) || !(op.stride == 1 || op.stride == 2) || op.cin < 8 || (op.cin & 7) ||
             op.cout < 4 || (op.cout & 3) || op.act < 0 || op.act > 2)
             return fail(h, FRP_ERR_BLOB, "op shape not supported");
-        const uint64_t wbytes = (uint64_t)op.cout * op.ksize * op.ksize * op.cin * 2;
+        const uint64_t welems = (uint64_t)op.cout * op.ksize * op.ksize * op.cin;
+        // fp8 storage: one byte per element, then (16-byte aligned) cout fp32 scales
+        const uint64_t wbytes = (op.flags & FRP_OPFLAG_W_FP8) ? ((welems + 15) / 16 * 16 + (uint64_t)op.cout * 4) : welems * 2;
         const uint64_t bbytes = (uint64_t)op.cout * 4 * ((op.flags & FRP_FLAG_BORDER_BIAS) ? 9 : 1);
         if (op.w_off < 0 || (uint64_t)op.w_off + wbytes > data_bytes || (op.w_off & 15) || op.bias_off < 0 ||
             (uint64_t)op.bias_off + bbytes > data_bytes || (op.bias_off & 15))
@@ -707,8 +740,37 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
     for (int l = 0; l < 3; ++l)
         if (hd.det_head_buf[l] >= hd.n_det_bufs) return fail(h, FRP_ERR_BLOB, "head buffer id out of range");
     if (hd.emb_out_buf >= hd.n_emb_bufs) return fail(h, FRP_ERR_BLOB, "embedding buffer id out of range");
-    FRPCHK(ensure(h, h->wdata, hd.data_bytes));
-    HIPCHK(h, hipMemcpyAsync(h->wdata.p, b + hd.data_offset, hd.data_bytes, hipMemcpyHostToDevice, h->stream));
+    // fp8-stored weights are expanded to fp16 behind the blob's data section (the kernels are the fp16 ones)
+    std::vector<unsigned char> expanded;
+    const unsigned char* data = b + hd.data_offset;
+    size_t data_bytes = hd.data_bytes;
+    bool any_fp8 = false;
+    for (Net* net : {&h->det, &h->emb})
+        for (const frp_conv_op& op : net->ops) any_fp8 |= (op.flags & FRP_OPFLAG_W_FP8) != 0;
+    if (any_fp8) {
+        expanded.assign(data, data + hd.data_bytes);
+        for (Net* net : {&h->det, &h->emb})
+            for (frp_conv_op& op : net->ops) {
+                if (!(op.flags & FRP_OPFLAG_W_FP8)) continue;
+                const size_t per_row = (size_t)op.ksize * op.ksize * op.cin, n = per_row * op.cout;
+                const size_t src = (size_t)op.w_off, sc = src + (n + 15) / 16 * 16;
+                size_t dst = (expanded.size() + 255) / 256 * 256;
+                expanded.resize(dst + n * 2);
+                uint16_t* out16 = reinterpret_cast<uint16_t*>(expanded.data() + dst);
+                for (int r = 0; r < op.cout; ++r) {
+                    float scale;
+                    memcpy(&scale, data + sc + (size_t)r * 4, 4);
+                    for (size_t i = 0; i < per_row; ++i)
+                        out16[(size_t)r * per_row + i] = f32_to_f16_bits(fp8_e4m3_value(data[src + (size_t)r * per_row + i]) * scale);
+                }
+                op.w_off = (int64_t)dst;
+                op.flags &= ~FRP_OPFLAG_W_FP8;
+            }
+        data = expanded.data();
+        data_bytes = expanded.size();
+    }
+    FRPCHK(ensure(h, h->wdata, data_bytes));
+    HIPCHK(h, hipMemcpyAsync(h->wdata.p, data, data_bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->hdr = hd;
     h->have_weights = true;

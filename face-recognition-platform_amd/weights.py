@@ -181,7 +181,63 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
     return phys, n
 
 
-def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3)) -> bytes:
+# ---------------------------------------------------------------------------- fp8 weight storage (BASELINE config 5)
+OPFLAG_W_FP8 = 16          # include/frp_blob.h: FRP_OPFLAG_W_FP8
+
+
+def _fp8_e4m3_table() -> np.ndarray:
+    """value of every OCP FP8 E4M3FN code (bias 7, no infinities, S.1111.111 = NaN)"""
+    t = np.zeros(256, np.float32)
+    for code in range(256):
+        sgn = -1.0 if code & 0x80 else 1.0
+        e, m = (code >> 3) & 0xF, code & 7
+        if e == 15 and m == 7:
+            v = np.nan
+        elif e == 0:
+            v = sgn * 2.0 ** -6 * (m / 8.0)
+        else:
+            v = sgn * 2.0 ** (e - 7) * (1.0 + m / 8.0)
+        t[code] = v
+    return t
+
+
+FP8_E4M3 = _fp8_e4m3_table()
+
+
+def fp8_e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """nearest E4M3FN code of each element (|x| <= 448), ties to the even code"""
+    x = np.asarray(x, np.float32)
+    pos = FP8_E4M3[:127]                                # codes 0..126: ascending magnitudes 0 .. 448
+    a = np.minimum(np.abs(x), np.float32(448.0))
+    hi = np.clip(np.searchsorted(pos, a, side="left"), 1, 126)
+    lo = hi - 1
+    dlo, dhi = a - pos[lo], pos[hi] - a
+    code = np.where((dlo < dhi) | ((dlo == dhi) & ((lo & 1) == 0)), lo, hi).astype(np.uint8)
+    return np.where(np.signbit(x) & (code != 0), code | 0x80, code).astype(np.uint8)
+
+
+def fp8_quantize_rows(w16: np.ndarray):
+    """per-output-channel E4M3 quantisation of a folded fp16 weight tensor [cout, ...]
+    -> (codes u8 same shape, scale fp32 [cout]); dequantised value = fp16(fp32(table[code]) * scale)"""
+    w = w16.astype(np.float32).reshape(w16.shape[0], -1)
+    amax = np.abs(w).max(axis=1)
+    scale = np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    codes = fp8_e4m3_encode(w / scale[:, None]).reshape(w16.shape)
+    return codes, scale
+
+
+def fp8_dequantize_rows(codes: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    v = FP8_E4M3[codes.reshape(codes.shape[0], -1)] * scale[:, None].astype(np.float32)
+    return v.astype(np.float32).astype(np.float16).reshape(codes.shape)
+
+
+def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3),
+              weight_format: str = "fp16", w16_hook=None) -> bytes:
+    """weight_format "fp8": conv/FC weights are stored as E4M3 bytes + one fp32 scale per output channel
+    (half the blob, half the upload); the library expands them to fp16 at load, the kernels are the fp16
+    ones.  `w16_hook(layer, w16) -> w16` lets tests substitute the folded fp16 weights of a layer."""
+    if weight_format not in ("fp16", "fp8"):
+        raise ValueError("weight_format must be 'fp16' or 'fp8'")
     det = ns.detector_layers(det_blocks)
     emb = ns.iresnet_layers(emb_blocks)
     data = bytearray()
@@ -198,11 +254,21 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
         ops = bytearray()
         for l in layers:
             w16, bias, slope = fold_layer(raw, l)
-            w_off = put(w16)
+            if w16_hook is not None:
+                w16 = w16_hook(l, w16)
+            flags = l.flags
+            if weight_format == "fp8":
+                codes, scale = fp8_quantize_rows(w16)
+                w_off = put(codes)
+                data.extend(b"\0" * ((-len(data)) % 16))
+                data.extend(scale.astype("<f4").tobytes())
+                flags |= OPFLAG_W_FP8
+            else:
+                w_off = put(w16)
             b_off = put(bias)
             s_off = put(slope) if slope is not None else -1
             ops += struct.pack(OP_FMT, phys[l.src], phys[l.dst], phys[l.res] if l.res else -1,
-                               l.cin, l.cout, l.k, l.stride, l.act, l.flags,
+                               l.cin, l.cout, l.k, l.stride, l.act, flags,
                                (l.cin_real or l.cin) | ((l.cout_real or l.cout) << 16), w_off, b_off, s_off)
         return bytes(ops), phys, nb
 

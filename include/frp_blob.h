@@ -8,6 +8,7 @@
 
 #define FRP_BLOB_MAGIC "FRPBLOB1"
 #define FRP_BLOB_VERSION 1u
+#define FRP_OPFLAG_W_FP8 16
 
 #pragma pack(push, 1)
 typedef struct frp_blob_header {      /* 128 bytes */
@@ -28,7 +29,11 @@ typedef struct frp_conv_op {          /* 64 bytes */
     int32_t cin, cout, ksize, stride; /* pad = ksize/2 */
     int32_t act;                      /* 0 none, 1 ReLU, 2 PReLU */
     int32_t flags;                    /* 1 border-class bias [9][cout], 2 fp32 output,
-                                         4 residual read at (y>>1,x>>1), 8 input viewed as 1x1x(H*W*C) */
+                                         4 residual read at (y>>1,x>>1), 8 input viewed as 1x1x(H*W*C),
+                                         16 (FRP_OPFLAG_W_FP8) weights stored as OCP FP8 E4M3FN bytes
+                                         [cout][k][k][cin] followed, at the next 16-byte boundary, by cout
+                                         fp32 per-output-channel scales: expanded to fp16 at load
+                                         (value = fp16(fp32(e4m3) * scale)); BASELINE config 5 */
     int32_t real_ch;                  /* cin_real | cout_real << 16 (unpadded channel counts, for flop accounting) */
     int64_t w_off, bias_off, slope_off; /* byte offsets into the data section; slope_off -1 = none */
 } frp_conv_op;

@@ -267,3 +267,42 @@ def test_arcface_checkpoint_loader_roundtrip(tmp_path):
     det = weights.make_synthetic_raw(11, (1, 1, 1, 1), (1, 2, 1, 1), want_emb=False)
     blob = weights.pack_blob({**det, **got}, (1, 1, 1, 1), weights.emb_blocks_of(got))
     assert blob[:8] == b"FRPBLOB1"
+
+
+def test_fp8_weight_codec_and_blob():
+    """BASELINE config 5 storage format: E4M3FN codec properties and the fp8 blob layout"""
+    import struct
+    from frp_amd import netspec as ns, weights as wts
+    t = wts.FP8_E4M3
+    assert t[0] == 0 and t[1] == 2.0 ** -9 and t[0x7E] == 448.0 and np.isnan(t[0x7F]) and t[0x80 | 0x7E] == -448.0
+    assert np.all(np.diff(t[:127]) > 0)                                   # codes 0..126 ascend
+    codes = np.arange(256, dtype=np.uint8)
+    ok = ~np.isnan(t)
+    back = wts.fp8_e4m3_encode(t[ok])
+    assert np.array_equal(t[back], t[ok])                                  # every representable value encodes to itself
+    assert wts.fp8_e4m3_encode(np.array([-0.0], np.float32))[0] == 0      # no negative zero codes
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-448, 448, 20000).astype(np.float32)
+    q = t[wts.fp8_e4m3_encode(x)]
+    assert np.all(np.abs(q - x) <= np.maximum(np.abs(x) * 2.0 ** -4, 2.0 ** -10))     # half an ulp of a 3-bit mantissa
+    mid = (t[8:126] + t[9:127]) / 2                                        # exact ties go to the even code
+    assert np.all(wts.fp8_e4m3_encode(mid.astype(np.float32)) % 2 == 0)
+    w = (rng.standard_normal((6, 3, 3, 16)) * 0.1).astype(np.float16)
+    w[2] = 0
+    c, s = wts.fp8_quantize_rows(w)
+    d = wts.fp8_dequantize_rows(c, s)
+    assert d.dtype == np.float16 and np.all(d[2] == 0) and s[2] == 1.0
+    assert np.abs(d.astype(np.float32) - w.astype(np.float32)).max() <= np.abs(w.astype(np.float32)).max() * 2.0 ** -4 * 1.01
+    # blob: same program, weights at one byte per element + scales, flag 16 on every op
+    raw = wts.make_synthetic_raw(3, (1, 1, 1, 1), (1, 1, 1, 1))
+    b16 = wts.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1))
+    b8 = wts.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1), weight_format="fp8")
+    assert len(b8) < 0.56 * len(b16)
+    hdr = struct.unpack(wts.HEADER_FMT, b8[:wts.HEADER_BYTES])
+    n_det, det_off = hdr[3], hdr[19]
+    op_size = struct.calcsize(wts.OP_FMT)
+    for i in range(n_det):
+        op = struct.unpack(wts.OP_FMT, b8[det_off + i * op_size: det_off + (i + 1) * op_size])
+        assert op[8] & wts.OPFLAG_W_FP8
+    with pytest.raises(ValueError):
+        wts.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1), weight_format="int4")
