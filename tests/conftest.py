@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# FaceService writes per-identity JSON backups (face_service.py:731-741 of the reference): keep the test
+# runs out of the working tree
+import tempfile
+os.environ.setdefault("FACE_BACKUP_DIR", tempfile.mkdtemp(prefix="frp_backups_"))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
