@@ -188,6 +188,13 @@ int plan_net(frp_handle* h, Net& net, int batch, int H, int W, bool skip_input =
         out.c = op.cout;
         out.f32 = (op.flags & FRP_FLAG_OUT_F32) != 0;
         if (out.h <= 0 || out.w <= 0) return fail(h, FRP_ERR_INVALID, "input too small for the network");
+        if (in.f32) return fail(h, FRP_ERR_BLOB, "program reads an fp32 tensor as a conv input");
+        if (op.res_buf >= 0) {                     // the epilogue reads the residual unchecked: validate it here
+            const TensorDims& r = net.dims[op.res_buf];
+            const bool up2 = (op.flags & FRP_FLAG_RES_UP2) != 0;
+            if (r.c != op.cout || r.f32 || (up2 ? (r.h * 2 != out.h || r.w * 2 != out.w) : (r.h != out.h || r.w != out.w)))
+                return fail(h, FRP_ERR_BLOB, "program residual shape mismatch");
+        }
         net.dims[op.out_buf] = out;
         need[op.out_buf] = std::max(need[op.out_buf], (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : 2));
     }

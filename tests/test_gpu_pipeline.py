@@ -321,3 +321,84 @@ def test_fp8_weight_blob(engine):
         engine.gallery_set(G)
         idx, _ = engine.match(e8)
         assert np.array_equal(idx, np.arange(100, 100 + len(e16)))
+
+
+def test_malformed_blobs_are_rejected_not_executed(engine):
+    """frp_load_weights / the planner validate everything a kernel would otherwise trust: every corruption
+    below must come back as an error (never a launch), and the engine must stay usable afterwards."""
+    import struct
+    from frp_amd import weights as wts
+    from frp_amd.native import FrpError
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    hdr = list(struct.unpack(wts.HEADER_FMT, blob[:wts.HEADER_BYTES]))
+    n_det, det_off, emb_off, data_off, data_bytes = hdr[3], hdr[19], hdr[20], hdr[21], hdr[22]
+    op_size = struct.calcsize(wts.OP_FMT)
+
+    def with_header(**kw):
+        h2 = list(hdr)
+        for k, v in kw.items():
+            h2[int(k[1:])] = v
+        return struct.pack(wts.HEADER_FMT, *h2) + blob[wts.HEADER_BYTES:]
+
+    def with_op(i, **kw):
+        names = ["in_buf", "out_buf", "res_buf", "cin", "cout", "ksize", "stride", "act", "flags", "real_ch", "w_off", "bias_off", "slope_off"]
+        off = det_off + i * op_size
+        op = list(struct.unpack(wts.OP_FMT, blob[off:off + op_size]))
+        for k, v in kw.items():
+            op[names.index(k)] = v
+        return blob[:off] + struct.pack(wts.OP_FMT, *op) + blob[off + op_size:]
+
+    ops = [struct.unpack(wts.OP_FMT, blob[det_off + i * op_size: det_off + (i + 1) * op_size]) for i in range(n_det)]
+    res_i = next(i for i, o in enumerate(ops) if o[2] >= 0 and not (o[8] & 4))        # a block conv with a plain residual
+    frames = np.zeros((1, 64, 64, 3), np.uint8)
+    load_time = {
+        "truncated": blob[:len(blob) // 2],
+        "tiny": blob[:40],
+        "magic": b"XRPBLOB1" + blob[8:],
+        "version": with_header(f1=99),
+        "data beyond file": with_header(f22=data_bytes + 4096),
+        "op table beyond file": with_header(f19=len(blob) - 8),
+        "head buffer id": with_header(f8=10 ** 6),
+        "buffer id": with_op(3, out_buf=10 ** 6),
+        "in == out": with_op(3, out_buf=ops[3][0]),
+        "weight offset": with_op(3, w_off=data_bytes - 16),
+        "bias offset": with_op(3, bias_off=data_bytes + 256),
+        "kernel size": with_op(3, ksize=5),
+        "stride": with_op(3, stride=3),
+        "activation": with_op(3, act=7),
+        "fp8 flag without room for the scales": with_op(n_det - 1, flags=ops[n_det - 1][8] | 16, w_off=data_bytes - 256),
+    }
+    for name, bad in load_time.items():
+        with pytest.raises(FrpError):
+            engine.load_weights(bad)
+        with pytest.raises(FrpError):                     # a failed load leaves no half-loaded program behind
+            engine.detect(frames, max_faces=2)
+    # plan-time corruptions: walk the program as the planner does (physical buffers are recycled) to pick
+    # buffers that are GUARANTEED inconsistent at that op
+    def dims_before(i, H=64, W=64):
+        d = {hdr[5]: (H, W, 8)}
+        for o in ops[:i]:
+            h, w, _ = d[o[0]]
+            k, st = o[5], o[6]
+            d[o[1]] = ((h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1, o[4])
+        return d
+    d_res = dims_before(res_i)
+    h, w, _ = d_res[ops[res_i][0]]
+    want = (h, w, ops[res_i][4])                                         # stride-1 3x3: output dims = input dims
+    wrong_res = next(b for b, dd in d_res.items() if dd != want and b != ops[res_i][1])
+    unwritten = next(b for b in range(hdr[4]) if b not in dims_before(2) and b != ops[2][1])
+    plan_time = {
+        "channel chain": with_op(4, cin=ops[4][3] * 2),
+        "residual shape": with_op(res_i, res_buf=wrong_res),
+        "reads an unwritten buffer": with_op(2, in_buf=unwritten),
+    }
+    for name, bad in plan_time.items():
+        try:
+            engine.load_weights(bad)
+        except FrpError:
+            continue                                       # rejected at load: fine too
+        with pytest.raises(FrpError):
+            engine.detect(frames, max_faces=2)
+    engine.load_weights(blob)                              # and a good blob still works
+    out = engine.detect(frames, max_faces=2)
+    assert out["counts"].shape == (1,)
