@@ -402,3 +402,40 @@ def test_malformed_blobs_are_rejected_not_executed(engine):
     engine.load_weights(blob)                              # and a good blob still works
     out = engine.detect(frames, max_faces=2)
     assert out["counts"].shape == (1,)
+
+
+def test_c_abi_rejects_bad_arguments(engine):
+    """every entry point returns a negative status (and a message) on null / out-of-range arguments
+    instead of touching memory"""
+    import ctypes as C
+    lib, h = engine._lib, engine._h
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    f = np.zeros((1, 64, 64, 3), np.uint8)
+    o = engine._alloc(1, 4)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)     # noqa: E731
+    outs = [ptr(o["boxes"]), ptr(o["kps"]), ptr(o["scores"]), ptr(o["counts"]), ptr(o["emb"]), ptr(o["match_idx"]), ptr(o["match_cos"])]
+    bad_calls = [
+        lambda: lib.frp_process_frames(h, None, 1, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),
+        lambda: lib.frp_process_frames(h, ptr(f), 0, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),
+        lambda: lib.frp_process_frames(h, ptr(f), 1, 64, 64, 100, 4, 0.5, 0.4, 0, *outs),          # row stride < W*3
+        lambda: lib.frp_process_frames(h, ptr(f), 1, 64, 64, 192, 0, 0.5, 0.4, 0, *outs),          # max_faces 0
+        lambda: lib.frp_process_frames(h, ptr(f), 1, 64, 64, 192, 1000, 0.5, 0.4, 0, *outs),       # max_faces > cap
+        lambda: lib.frp_process_frames(h, ptr(f), 5000, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),       # batch too large
+        lambda: lib.frp_upload_frames(h, None, 1, 64, 64, 192),
+        lambda: lib.frp_upload_frames_async(h, ptr(f), 1, -3, 64, 192),
+        lambda: lib.frp_match(h, None, 1, 1, ptr(o["match_idx"]), ptr(o["match_cos"])),
+        lambda: lib.frp_match_scores(h, ptr(o["emb"]), 1, None),
+        lambda: lib.frp_gallery_set(h, None, 5, 512, 0),
+        lambda: lib.frp_gallery_set(h, ptr(o["emb"]), 1, 128, 0),                                 # wrong dimension
+        lambda: lib.frp_gallery_remove_row(h, 10 ** 9),
+        lambda: lib.frp_load_weights(h, None, 100),
+        lambda: lib.frp_embed_aligned(h, None, 3, ptr(o["emb"])),
+        lambda: lib.frp_conv2d_nhwc(h, ptr(f), 1, 8, 8, 24, ptr(f), 32, 3, 1, ptr(o["scores"]), None, None, 0, 0, 0, 0, ptr(o["emb"])),
+        lambda: lib.frp_process_frames(None, ptr(f), 1, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),      # null handle
+    ]
+    for i, call in enumerate(bad_calls):
+        assert call() < 0, i
+    assert lib.frp_last_error(h)                      # a message is kept for the last failure on this handle
+    res = engine.process_frames(f, max_faces=4)       # still alive
+    assert res["counts"].shape == (1,)
