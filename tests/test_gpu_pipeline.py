@@ -439,3 +439,37 @@ def test_c_abi_rejects_bad_arguments(engine):
     assert lib.frp_last_error(h)                      # a message is kept for the last failure on this handle
     res = engine.process_frames(f, max_faces=4)       # still alive
     assert res["counts"].shape == (1,)
+
+
+def test_one_handle_shared_by_threads(engine):
+    """the reference calls the service from a 4-thread pool (routes/camera.py:30,277-279): concurrent callers
+    of ONE handle are serialised by its mutex and every caller gets its own, correct result"""
+    import threading
+    rng = np.random.default_rng(31)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    engine.gallery_set(rng.standard_normal((500, 512)).astype(np.float32))
+    jobs = [(_frames(rng, 2, 96 + 32 * (i % 2), 160), rng.integers(0, 256, (3, 112, 112, 3), dtype=np.uint8)) for i in range(4)]
+    want = [(engine.process_frames(f, max_faces=3, flags=1), engine.embed_aligned(c)) for f, c in jobs]
+    got = [None] * 4
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                a = engine.process_frames(jobs[i][0], max_faces=3, flags=1)
+                b = engine.embed_aligned(jobs[i][1])
+                got[i] = (a, b)
+        except Exception as e:              # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        for key in ("boxes", "kps", "emb", "match_idx", "match_cos", "counts"):
+            assert np.array_equal(got[i][0][key], want[i][0][key]), (i, key)
+        assert np.array_equal(got[i][1], want[i][1])
