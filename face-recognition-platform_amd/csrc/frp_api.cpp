@@ -56,6 +56,7 @@ struct frp_handle {
     // resident frames (tightly packed u8 [B,H,W,3])
     DevBuf frames;
     int rB = 0, rH = 0, rW = 0;
+    int n_cu = 256;                   // compute units of the device (queried once at create)
     // overlapped ingest: the NEXT batch is copied on its own stream while the current one is processed
     DevBuf frames_next;
     int nB = 0, nH = 0, nW = 0;
@@ -313,10 +314,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         // the l2norm kernel that follows
         h->fc_ksplit = 0;
         if ((op.flags & FRP_FLAG_OUT_F32) && &op == &net.ops.back() && !getenv("FRP_NO_SPLITK")) {
-            int dev = 0, ncu = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ncu = prop.multiProcessorCount;
+            const int ncu = h->n_cu;
             const int ks = conv_pick_ksplit(batch * ((in.h + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1) *
                                                 ((in.w + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1),
                                             op.cout, op.ksize * op.ksize * op.cin, op.flags, op.res_buf >= 0, ncu);
@@ -698,6 +696,10 @@ int frp_create(int device, const frp_config* cfg, frp_handle** out) {
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->h_nfaces, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+    }
     ok = ok && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_next_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_next_free, hipEventDisableTiming) == hipSuccess;
@@ -732,6 +734,7 @@ const char* frp_last_error(const frp_handle* h) { return h ? h->err.c_str() : "n
 int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    h->have_weights = false;          // a failed load never leaves a half-replaced program runnable
     if (!blob || bytes < sizeof(frp_blob_header)) return fail(h, FRP_ERR_BLOB, "blob too small");
     frp_blob_header hd;
     memcpy(&hd, blob, sizeof(hd));
@@ -740,7 +743,6 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
     if (hd.data_offset > bytes || hd.data_bytes > bytes - hd.data_offset) return fail(h, FRP_ERR_BLOB, "data section out of range");
     if (hd.emb_dim != FRP_EMB_DIM || hd.emb_size != FRP_CHIP || hd.det_in_ch != 8 || hd.emb_in_ch != 8 || hd.det_num_anchors != 2)
         return fail(h, FRP_ERR_BLOB, "unsupported network geometry");
-    h->have_weights = false;
     const unsigned char* b = (const unsigned char*)blob;
     FRPCHK(parse_net(h, b, bytes, hd.det_ops_offset, hd.n_det_ops, hd.n_det_bufs, hd.det_in_buf, hd.det_in_ch, hd.data_bytes, h->det));
     FRPCHK(parse_net(h, b, bytes, hd.emb_ops_offset, hd.n_emb_ops, hd.n_emb_bufs, hd.emb_in_buf, hd.emb_in_ch, hd.data_bytes, h->emb));

@@ -17,27 +17,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "frp_internal.h"
+#include "conv_common.h"
 
 namespace frp {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
+// (vector typedefs and the half-wave exchange `swap_halves` come from conv_common.h)
 
 #define ST_ROWS 4
 #define ST_COLS 64
 #define ST_PR (2 * ST_ROWS + 1)          // patch rows
 #define ST_PE ((2 * ST_COLS + 1) * 3)    // patch elements per row (387)
 #define ST_PITCH 392                     // halfs per patch row
-
-// exchange between the half-waves so that each lane ends up with 16 contiguous output bytes
-// (lane<32: couts 16q..16q+7, lane>=32: couts 16q+8..16q+15 of its pixel) instead of two 8-byte runs
-__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
-}
 
 __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -392,10 +382,9 @@ hipError_t launch_stem12_u8(const Stem12Params& p, hipStream_t stream) {
     const long tiles = (long)p.B * ((p.Ho2 + S12_R2 - 1) / S12_R2) * ((p.Wo2 + S12_C2 - 1) / S12_C2);
     if (tiles <= 0 || tiles > 0x7fffffffL) return hipErrorInvalidValue;
     int dev = 0;
-    hipDeviceProp_t prop;
-    int ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        ncu = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const int ncu = device_cu_count(dev);             // cached per device
+    if (ncu <= 0) return hipErrorInvalidDevice;
     const long slots = 2L * ncu;                      // persistent: two workgroups per CU (63 KiB LDS each)
     hipLaunchKernelGGL(stem12_u8_kernel, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -91,7 +91,9 @@ const char* frp_version(void);
 
 /* Weight blob (layout: include/frp_blob.h; produced by weights.pack_blob):
  * folded fp16 conv programs of the detector and the embedder.
- * replaces: insightface FaceAnalysis model-pack loading (deepfake_utils.py:39-51). */
+ * replaces: insightface FaceAnalysis model-pack loading (deepfake_utils.py:39-51).
+ * A failed load leaves the handle WITHOUT weights (FRP_ERR_NO_WEIGHTS on later compute calls), never with a
+ * half-replaced program. */
 int frp_load_weights(frp_handle* h, const void* blob, size_t bytes);
 
 /* ---- gallery (watchlist embedding matrix) -----------------------------------------

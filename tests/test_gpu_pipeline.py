@@ -437,6 +437,10 @@ def test_c_abi_rejects_bad_arguments(engine):
     for i, call in enumerate(bad_calls):
         assert call() < 0, i
     assert lib.frp_last_error(h)                      # a message is kept for the last failure on this handle
+    from frp_amd.native import FrpError
+    with pytest.raises(FrpError):                     # the failed frp_load_weights above unloaded the program
+        engine.process_frames(f, max_faces=4)
+    engine.load_weights(blob)
     res = engine.process_frames(f, max_faces=4)       # still alive
     assert res["counts"].shape == (1,)
 
