@@ -121,22 +121,40 @@ __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
         const float fx0 = floorf(sx), fy0 = floorf(sy);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const float ax = sx - fx0, ay = sy - fy0;
-        float acc[3] = {0.f, 0.f, 0.f};
-        if (ok) {
+        // Both taps of an image row are 6 contiguous bytes: ONE unaligned 8-byte load per row from a clamped
+        // (always valid) address instead of 6 byte loads (the gather was bound by load instructions: one
+        // lane-address per clock).  An out-of-image tap gets weight 0 (adds an exact +0: border value 0, same
+        // bits as skipping it); loads are unconditional so both rows are in flight together.
+        unsigned char tap[4][3];
+        float wgt[4];
+        const int bx_max = 3 * p.W - 8;                                     // last byte offset an 8-byte read may start at
+        int bx = 3 * x0;
+        bx = bx < 0 ? 0 : (bx > bx_max ? bx_max : bx);
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
+        for (int dy = 0; dy < 2; ++dy) {
+            const int yy = y0 + dy;
+            const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+            unsigned long long v;
+            __builtin_memcpy(&v, img + (long)yc * p.row_stride + bx, 8);    // unaligned 64-bit global load
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int xx = x0 + dx, yy = y0 + dy;
-                    if ((unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H) {
-                        const float w = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
-                        const uint8_t* px = img + yy * p.row_stride + 3L * xx;
-                        acc[0] += w * (float)px[c_r];
-                        acc[1] += w * (float)px[1];
-                        acc[2] += w * (float)px[c_b];
-                    }
-                }
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = x0 + dx;
+                const bool inside = ok && (unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H;
+                int o = 3 * xx - bx;                                        // byte offset of this tap inside v
+                o = o < 0 ? 0 : (o > 5 ? 5 : o);                            // (only out-of-image taps get clamped)
+                const unsigned pix = (unsigned)(v >> (8 * o));
+                tap[dy * 2 + dx][0] = (unsigned char)(pix >> (8 * c_r));
+                tap[dy * 2 + dx][1] = (unsigned char)(pix >> 8);
+                tap[dy * 2 + dx][2] = (unsigned char)(pix >> (8 * c_b));
+                wgt[dy * 2 + dx] = inside ? (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay) : 0.f;
             }
+        }
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[0] += wgt[k] * (float)tap[k][0];
+            acc[1] += wgt[k] * (float)tap[k][1];
+            acc[2] += wgt[k] * (float)tap[k][2];
         }
         half8 o;
         o[0] = (_Float16)((acc[0] - 127.5f) * (1.0f / 127.5f));
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
 
 hipError_t launch_align(const AlignParams& p, hipStream_t stream) {
     if (p.n_faces <= 0) return hipSuccess;
-    if (!p.frames || !p.kps || !p.chips || p.H <= 0 || p.W <= 0) return hipErrorInvalidValue;
+    if (!p.frames || !p.kps || !p.chips || p.H <= 0 || p.W < 3) return hipErrorInvalidValue;   // 8-byte row reads need 3*W >= 8
     hipLaunchKernelGGL(align_kernel, dim3(p.n_faces * ALIGN_SPLIT), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
