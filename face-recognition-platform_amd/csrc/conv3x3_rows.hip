@@ -49,8 +49,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     const int n_tiles = p.n_ptiles * p.n_ctiles;
-    const int t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
-    const int t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+    // Tile walk.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  XCD x takes the
+    // contiguous chunk [x*T/8, (x+1)*T/8) of the tile list and its G/8 workgroups walk it INTERLEAVED (workgroup
+    // j: chunk + j, + j + G/8, ...): at any moment the workgroups of one L2 work on G/8 consecutive tiles, i.e. on
+    // a band of neighbouring image rows whose kh = 0/1/2 row patches (and both cout tiles of a pixel tile) are the
+    // same lines - fetched once per L2 instead of once per workgroup several tiles apart.
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = per;
+    } else {                                        // small grids (fewer tiles than CUs): contiguous ranges
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
     if (t0 >= t1) return;
     const int cpt = p.Cin >> 6;                // 64-channel blocks
 
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             x_kh = 0;
             if (++x_cb == cpt) {
                 x_cb = 0;
-                if (++xt < t1) setup_x_tile(xt); else x_live = false;
+                if ((xt += tstep) < t1) setup_x_tile(xt); else x_live = false;
             }
         }
     };
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             w_tap = 0;
             if (++w_cb == cpt) {
                 w_cb = 0;
-                if (++wt < t1) setup_w_tile(wt); else w_live = false;
+                if ((wt += tstep) < t1) setup_w_tile(wt); else w_live = false;
             }
         }
     };
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     };
 
     stamp(p.stamps, 1);
-    for (int ct = t0; ct < t1; ++ct) {
+    for (int ct = t0; ct < t1; ct += tstep) {
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
