@@ -26,9 +26,9 @@ HBM_PEAK_GBS = 8000.0
 
 def pmc_conv_traffic_per_launch(launches_per_step):
     """HBM-side bytes per conv launch from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r1/pmc_traffic_v6.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
+    command (profiles/r1/pmc_traffic_v7.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected
     in separate passes as the microarch guide prescribes).  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v6.json")
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_v7.json")
     try:
         with open(path) as f:
             t = json.load(f)

@@ -27,8 +27,8 @@
 //   * the LDS image is rows of 128 B with chunk ^= (row>>1)&7 (conflict-free for the
 //     ds_read_b128 fragment reads); the DMA destination is lane-linear, so the swizzle is
 //     applied to the per-lane SOURCE chunk;
-//   * each persistent workgroup walks a contiguous range of tiles with the cout tiles of one pixel
-//     tile back to back, and k runs (64-channel block, kh, kw): the nine taps of a channel block
+//   * persistent workgroups walk the tile list XCD-interleaved (neighbouring tiles, incl. the cout tiles of
+//     one pixel tile, are in flight on the same L2 together), and k runs (64-channel block, kh, kw): the nine taps of a channel block
 //     re-read nearly the same input lines within nine consecutive k-steps, so they hit in L2
 //     (tap-major order thrashed the 4 MiB L2 on Cin >= 128: 2-10x the algorithmic reads);
 //   * 3x3 stride-1 layers with Cin % 64 == 0 go to conv3x3_rows.hip (row patches) instead.
@@ -64,8 +64,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
     // (tile, k-slice) pair: slice s covers k-steps [s*nk, (s+1)*nk) and writes raw fp32 partial
     // sums to a workspace slab that a finalize kernel reduces.
     const int n_tiles = p.n_ptiles * p.n_ctiles * p.ksplit;
-    const int t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
-    const int t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+    // XCD-interleaved walk (see conv3x3_rows.hip): the workgroups of one L2 (b, b+8, ...) share a contiguous
+    // chunk of the tile list and walk it interleaved, so neighbouring tiles - same input rows, both cout tiles of
+    // a pixel tile, the k-slices of one split-K tile - are in flight on the same L2 at the same time.
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = per;
+    } else {
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
     if (t0 >= t1) return;
     const int nk = p.nk / p.ksplit;            // k-steps per (tile, slice); launch_conv makes it exact
 
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
         ibuf = ibuf == NS - 1 ? 0 : ibuf + 1;
         if (++iks == nk) {
             iks = 0;
-            if (++it < t1) setup_issue_tile(it);
+            if ((it += tstep) < t1) setup_issue_tile(it);
         }
     };
     // piece j of a stage: j < XI -> pixel rows, else weight rows (j is a literal at every use)
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
     };
 
     // ---------------- the stage stream: NS-slot ring, one barrier per k-step, continuous over tiles
-    const int total = (t1 - t0) * nk;          // stages this workgroup consumes
+    const int total = ((t1 - t0 + tstep - 1) / tstep) * nk;   // stages this workgroup consumes
     stamp(p.stamps, 0);
     setup_issue_tile(t0);
     int issued = 0;
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
     const bool relu = p.act == FRP_ACT_RELU;
 
     stamp(p.stamps, 1);
-    for (int ct = t0; ct < t1; ++ct) {
+    for (int ct = t0; ct < t1; ct += tstep) {
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
