@@ -299,6 +299,59 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(const _Float16* __restri
     dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The conv k-step without memory traffic or barriers: 8 waves per CU (2 per SIMD), each a 64x64 tile = 16 MFMAs
+// per step fed by READS ds_read_b128 per group of 4 MFMAs (4 = the conv kernels: one read per MFMA; 3 / 2 =
+// what larger per-wave tiles would need), fragments double-buffered as in the kernels.  What this loop sustains
+// is the ceiling of that wave layout on this device.
+template <int READS>
+__global__ __launch_bounds__(512, 2) void mfma_lds_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 384 * 128];      // the 3-slot ring of the 256x128 tile
+    for (int i = threadIdx.x; i < 3 * 384 * 128 / 16; i += 512)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[i];     // 144 KiB of random fp16
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int prow0 = (wave >> 1) * 64, crow0 = 256 + (wave & 1) * 64;
+    floatx16_ acc[2][2] = {};
+    half8 f[2][4];
+    auto rd = [&](int stage, int kk, int S) {
+        const unsigned char* base = lds + stage * (384 * 128);
+#pragma unroll
+        for (int q = 0; q < READS; ++q) {
+            const int row = (q < 2 ? prow0 + q * 32 : crow0 + (q - 2) * 32) + fr;
+            f[S][q] = *reinterpret_cast<const half8*>(base + row * 128 + (((2 * kk + fh) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int q = READS; q < 4; ++q) f[S][q] = f[S][q - READS];                  // fewer reads: reuse a fragment
+    };
+    auto mm = [&](int S) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[S][2], f[S][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[S][3], f[S][0], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[S][2], f[S][1], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[S][3], f[S][1], acc[1][1], 0, 0, 0);
+    };
+    int stage = 0;
+    for (int it = 0; it < iters; ++it) {
+        rd(stage, 0, 0);
+        rd(stage, 1, 1); mm(0);
+        rd(stage, 2, 0); mm(1);
+        rd(stage, 3, 1); mm(0);
+        mm(1);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    float s = 0.f;
+    for (int e = 0; e < 16; ++e) s += acc[0][0][e] + acc[0][1][e] + acc[1][0][e] + acc[1][1][e];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+hipError_t launch_mfma_lds(const _Float16* src, float* dst, int blocks, int reads, int iters, hipStream_t stream) {
+    if (reads == 4) hipLaunchKernelGGL(mfma_lds_kernel<4>, dim3(blocks), dim3(512), 0, stream, src, dst, iters);
+    else if (reads == 3) hipLaunchKernelGGL(mfma_lds_kernel<3>, dim3(blocks), dim3(512), 0, stream, src, dst, iters);
+    else if (reads == 2) hipLaunchKernelGGL(mfma_lds_kernel<2>, dim3(blocks), dim3(512), 0, stream, src, dst, iters);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream) {
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, iters);
     return hipGetLastError();

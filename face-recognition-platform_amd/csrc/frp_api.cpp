@@ -1368,18 +1368,27 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
 int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    if (!tflops || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return fail(h, FRP_ERR_INVALID, "bad arguments");
-    const int blocks = 256 * waves_per_simd;   // 256 CUs x (4 waves per block = one per SIMD)
+    // waves_per_simd 1..8: register-operand loop.  16*r + 2 (r = 4, 3, 2): the conv k-step mix - 8 waves per CU,
+    // r ds_read_b128 per 4 MFMAs - one 512-thread block per CU
+    const int lds_reads = waves_per_simd >> 4;
+    if (lds_reads) waves_per_simd &= 15;
+    if (!tflops || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8 || (lds_reads && (waves_per_simd != 2 || lds_reads < 2 || lds_reads > 4)))
+        return fail(h, FRP_ERR_INVALID, "bad arguments");
+    const int blocks = lds_reads ? h->n_cu : 256 * waves_per_simd;   // 256 CUs x (4 waves per block = one per SIMD)
     DevBuf src, dst;
-    int rc = ensure(h, src, 4096);
-    if (rc == FRP_OK) rc = ensure(h, dst, (size_t)blocks * 256 * 4);
+    int rc = ensure(h, src, 3 * 384 * 128);
+    if (rc == FRP_OK) rc = ensure(h, dst, (size_t)blocks * 512 * 4);
     hipError_t e = hipSuccess;
     float ms = 0.f;
     if (rc == FRP_OK) {
-        e = launch_fill_random_f16((_Float16*)src.p, 2048, 7u, 1.0f, h->stream);
-        if (e == hipSuccess) e = launch_mfma_peak((const _Float16*)src.p, (float*)dst.p, blocks, iters, h->stream);
+        e = launch_fill_random_f16((_Float16*)src.p, 3 * 384 * 64, 7u, 1.0f, h->stream);
+        auto run = [&]() {
+            return lds_reads ? launch_mfma_lds((const _Float16*)src.p, (float*)dst.p, blocks, lds_reads, iters, h->stream)
+                             : launch_mfma_peak((const _Float16*)src.p, (float*)dst.p, blocks, iters, h->stream);
+        };
+        if (e == hipSuccess) e = run();
         if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
-        if (e == hipSuccess) e = launch_mfma_peak((const _Float16*)src.p, (float*)dst.p, blocks, iters, h->stream);
+        if (e == hipSuccess) e = run();
         if (e == hipSuccess) e = hipEventRecord(h->ev[1], h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
@@ -1389,7 +1398,7 @@ int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* t
     release(dst);
     if (rc != FRP_OK) return rc;
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("mfma_peak: ") + hipGetErrorString(e));
-    *tflops = (float)((double)blocks * 4 * iters * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+    *tflops = (float)((double)blocks * (lds_reads ? 8.0 * 16 : 4.0 * 4) * iters * 32768.0 / (ms * 1e-3) / 1e12);
     return FRP_OK;
 }
 

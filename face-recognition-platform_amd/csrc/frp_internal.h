@@ -135,6 +135,8 @@ int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_c
 hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
 
 hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream);
+// the conv k-step's MFMA + ds_read_b128 mix without memory traffic or barriers (reads per 4 MFMAs: 4, 3 or 2)
+hipError_t launch_mfma_lds(const _Float16* src, float* dst, int blocks, int reads, int iters, hipStream_t stream);
 hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream);
 
 // K6: cosine match, top-1 (and optional full score matrix)

@@ -394,6 +394,11 @@ class Engine:
         self._chk(self._lib.frp_mfma_peak(self._h, waves_per_simd, iters, C.byref(t)))
         return float(t.value)
 
+    def mfma_lds_peak(self, reads_per_4_mfma: int = 4, iters: int = 5000) -> float:
+        """TFLOP/s of the conv k-step's instruction mix alone (8 waves per CU, 64x64 wave tiles, fragments from LDS
+        by ds_read_b128, random data, no DMA / barriers / epilogue): the ceiling of that wave layout"""
+        return self.mfma_peak(16 * int(reads_per_4_mfma) + 2, iters)
+
     def counters(self) -> dict:
         c = FrpCounters()
         self._chk(self._lib.frp_get_counters(self._h, C.byref(c)))

@@ -201,7 +201,8 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
                    int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg,
                    uint64_t* stamps_out /* NULL, or [256][8] per-workgroup 100 MHz phase stamps of the last launch */);
 
-/* tuning hook: sustained v_mfma_f32_32x32x16_f16 rate of this device on register operands */
+/* tuning hook: sustained v_mfma_f32_32x32x16_f16 rate of this device on register operands (waves_per_simd 1..8),
+ * or - waves_per_simd = 16*r + 2, r in {4,3,2} - of the conv k-step's mix: 8 waves per CU, r ds_read_b128 per 4 MFMAs */
 int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops);
 
 /* ---- observability ---------------------------------------------------------------
