@@ -477,3 +477,22 @@ def test_one_handle_shared_by_threads(engine):
         for key in ("boxes", "kps", "emb", "match_idx", "match_cos", "counts"):
             assert np.array_equal(got[i][0][key], want[i][0][key]), (i, key)
         assert np.array_equal(got[i][1], want[i][1])
+
+
+def test_full_size_detector_vs_oracle_one_frame(engine):
+    """the full detector on true 1080p frames (maps 544x960 ... 34x60: every wide-image path of the row-patch
+    kernel, the XCD tile walk, the fused stems at full size) against the fp32 oracle, frame 0 of a batch of 3"""
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(77)
+    frames = rng.integers(0, 256, size=(3, 1080, 1920, 3), dtype=np.uint8)
+    frames[1:] = frames[0]                                   # batch entries 1, 2 repeat frame 0
+    engine.detect(frames, max_faces=4, det_thresh=0.5)
+    heads = engine.head_maps()
+    ref = onet.det_forward(raw, onet.det_blob(frames[:1], (1088, 1920)))
+    for g, r in zip(heads, ref):
+        assert g.shape[1:3] == r.shape[1:3]
+        scale = max(1.0, float(np.abs(r).max()))
+        err = np.abs(g[0, ..., :30].astype(np.float32) - r[0]).max()
+        assert err < 2e-2 * scale, (err, scale)
+        assert np.array_equal(g[0], g[1]) and np.array_equal(g[0], g[2])     # position in the batch does not matter
