@@ -340,3 +340,20 @@ def test_match_topk_rejects_bad_k(engine):
         engine.match(np.ones((1, 512), np.float32), topk=0)
     with pytest.raises(FrpError):
         engine.match(np.ones((1, 512), np.float32), topk=65)
+
+
+def test_embedder_large_batch_equals_small_batch_and_oracle(engine):
+    """IResNet-100 on 330 faces (every stage spans several tiles per workgroup: XCD-interleaved walk, ragged last
+    tiles) gives, face by face, the result of a 3-face call up to the fp32 summation order of the FC (its split-K
+    factor depends on the batch), which the fp32 oracle confirms"""
+    rng = np.random.default_rng(404)
+    chips = rng.integers(0, 256, size=(330, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (3, 13, 30, 3))
+    engine.load_weights(blob)
+    big = engine.embed_aligned(chips)
+    pick = [0, 151, 329]
+    small = engine.embed_aligned(chips[pick])
+    assert np.abs(big[pick] - small).max() < 1e-6
+    ref = onet.emb_forward(raw, onet.emb_blob(chips[pick]))
+    assert (small * ref).sum(1).min() > 1 - 1e-3
+    assert np.abs(np.linalg.norm(big, axis=1) - 1).max() < 1e-4
