@@ -29,7 +29,15 @@
 
 namespace frp {
 
-template <int TC, int WP, int WC>
+// PF = true: cross-barrier fragment prefetch.  The kk = 0 fragments of k-step s+1 are requested before the last
+// MFMA group of step s, so the first MFMAs after the barrier issue at once instead of sitting out an LDS round
+// trip with every wave of the CU in the same state (2 waves per SIMD, both behind the barrier: nothing feeds the
+// matrix pipe for ~150-250 of a step's ~1100 cycles).  That needs the k = 0..15 slice of the NEXT weight stage
+// in LDS one barrier early; instead of a fourth ring slot the weight stages are SHIFTED by a quarter: stage s
+// holds chunks 2..7 (kk = 1..3) of step s and, in chunk positions 0..1, kk = 0 of step s+1 - the DMA source
+// address is per lane, so lanes carrying logical chunks 0/1 simply run their cursor one step ahead.  The pixel
+// side needs nothing: the row patches are resident two row steps ahead anyway.
+template <int TC, int WP, int WC, bool PF>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int TP = 256, NW = 8;
@@ -110,10 +118,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         }
     };
 
-    // W cursor: runs two k-steps ahead; one stage = TC rows x 64 k of tap (kh, kw), block cb
+    // W cursor: runs two k-steps ahead; one stage = TC rows x 64 k of tap (kh, kw), block cb.
+    // PF: the cursor is the position of the stage's kk = 0 quarter (one step AHEAD of its kk = 1..3 part);
+    // voffC[] keeps the per-lane offsets the cursor had one step ago for the lanes carrying chunks 2..7.
     int wt = t0, w_cb = 0, w_tap = 0, w_slot = 0;
-    bool w_live = true;
-    unsigned woff[WI];
+    bool w_live = true;                        // PF: the kk = 0 (ahead) cursor is inside this workgroup's tiles
+    bool c_live = !PF;                         // PF: the stage's own step exists (= w_live one step ago)
+    const bool is0 = lchunk < 2;               // this lane carries logical chunk 0/1 (kk = 0)
+    unsigned woff[WI], voffC[WI], voffN[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) voffC[i] = voffN[i] = CONV_OOB;
     auto setup_w_tile = [&](int tile) {
         const int c0i = (tile % p.n_ctiles) * TC;
 #pragma unroll
@@ -122,12 +136,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
         }
     };
-    auto w_piece = [&](int i) {
+    // per-lane source offsets of the stage under the cursor (once per k-step, before its pieces are fired)
+    auto prep_w = [&]() {
         const unsigned kadd = (unsigned)((w_tap * cpt + w_cb) << 7);
-        dma16(wrsrc, smem + OFF_W + w_slot * WSLOT + (i * NW + wave) * 1024, woff[i] != CONV_OOB ? woff[i] + kadd : CONV_OOB);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) voffN[i] = (w_live && woff[i] != CONV_OOB) ? woff[i] + kadd : CONV_OOB;
+    };
+    auto w_piece = [&](int i) {
+        if constexpr (PF) {
+            dma16(wrsrc, smem + OFF_W + w_slot * WSLOT + (i * NW + wave) * 1024, is0 ? voffN[i] : voffC[i]);
+        } else {
+            const unsigned kadd = (unsigned)((w_tap * cpt + w_cb) << 7);
+            dma16(wrsrc, smem + OFF_W + w_slot * WSLOT + (i * NW + wave) * 1024, woff[i] != CONV_OOB ? woff[i] + kadd : CONV_OOB);
+        }
     };
     auto advance_w = [&]() {
         w_slot = w_slot == NWS - 1 ? 0 : w_slot + 1;
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < WI; ++i) voffC[i] = voffN[i];
+            c_live = w_live;
+            if (!w_live) return;
+        }
         if (++w_tap == 9) {
             w_tap = 0;
             if (++w_cb == cpt) {
@@ -218,13 +248,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         for (int q = 0; q < 5; ++q) x_piece(q);
         advance_x();
     }
+    // PF: three shifted stages (-1: only the kk = 0 quarter of step 0; 0; 1), stage s in slot (s + 1) % 3
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < (PF ? 3 : 2); ++s) {
+        if constexpr (PF) prep_w();
 #pragma unroll
         for (int i = 0; i < WI; ++i) w_piece(i);
         advance_w();
     }
-    int cx_slot = 0, cw_slot = 0;              // consumer ring positions
+    int cx_slot = 0, cw_slot = PF ? 1 : 0;     // consumer ring positions
     int last_cnt = -1;                         // pieces this wave fired in the previous k-step (-1: drain)
     const bool out32 = p.flags & FRP_FLAG_OUT_F32;
     const bool up2 = p.flags & FRP_FLAG_RES_UP2;
@@ -385,32 +417,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         // One k-step: wait for this wave's share of the stage, barrier (every wave's share landed;
         // every wave is done with the slots the next issues overwrite), 4 x (fragment reads, MFMA
         // group) with this step's DMA pieces fired in between.
-#define ROWS_STEP(KW, FIRST, LASTSTEP)                                                                          \
+        // PF, top of a tile: request the kk = 0 fragments of its first k-step (weights: last quarter of the
+        // previous stage's slot; pixels: the resident first row patch).  Both are visible since the previous
+        // step's barrier; the very first tile needs the prologue's DMA landed and a barrier of its own.
+        if constexpr (PF) {
+            if (ct == t0) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+            const int xs0 = cx_slot * XSLOT;
+#pragma unroll
+            for (int i = 0; i < MP; ++i) bbase[i] = (tapmask[i] & 1u) ? xs0 + brow[0][i] : OFF_Z + (brow[0][i] & 128);
+            read_frags(OFF_W + (cw_slot == 0 ? NWS - 1 : cw_slot - 1) * WSLOT, 0, 0, 0);
+        }
+
+#define ROWS_WAIT()                                                                                   \
     do {                                                                                              \
         if (last_cnt == WI + 2) wait_vmcnt<WI + 2>();                                                 \
         else if (last_cnt == WI + 1) wait_vmcnt<WI + 1>();                                            \
         else if (last_cnt == WI) wait_vmcnt<WI>();                                                    \
         else wait_vmcnt<0>();                                                                         \
+    } while (0)
+#define ROWS_STEP(KW, FIRST, LASTSTEP)                                                                \
+    do {                                                                                              \
+        ROWS_WAIT();                                                                                  \
+        /* PF: the prefetched fragments are in registers, so the slot they came from may be refilled */ \
+        if constexpr (PF) wait_lgkmcnt0();                                                            \
         __builtin_amdgcn_s_barrier();                                                                 \
         const int xsoff = cx_slot * XSLOT;                                                            \
         const int wsoff = OFF_W + cw_slot * WSLOT;                                                    \
-        _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                \
-            bbase[i] = ((tapmask[i] >> (kh * 3 + (KW))) & 1u) ? xsoff + brow[KW][i] : OFF_Z + (brow[KW][i] & 128); \
+        if constexpr (!PF) {                                                                          \
+            _Pragma("unroll") for (int i = 0; i < MP; ++i)                                            \
+                bbase[i] = ((tapmask[i] >> (kh * 3 + (KW))) & 1u) ? xsoff + brow[KW][i] : OFF_Z + (brow[KW][i] & 128); \
+        }                                                                                             \
         if (FIRST) fetch_params(ct);                                                                  \
         if ((LASTSTEP) && has_res) issue_residual_loads(m0, c0);                                      \
-        read_frags(wsoff, KW, 0, 0);                                                                  \
+        if constexpr (!PF) read_frags(wsoff, KW, 0, 0);                                               \
         int cnt = 0;                                                                                  \
+        const bool wfire = PF ? (c_live || w_live) : w_live;                                          \
+        if constexpr (PF) prep_w();                                                                   \
         /* weight pieces first: their slack is two k-steps at best, the row patches have six */      \
         read_frags(wsoff, KW, 1, 1); mfma_group(0);                                                   \
-        if (w_live) { w_piece(0); ++cnt; }                                                            \
-        if (WI == 2 && w_live) { w_piece(WI - 1); ++cnt; }                                            \
+        if (wfire) { w_piece(0); ++cnt; }                                                             \
+        if (WI == 2 && wfire) { w_piece(WI - 1); ++cnt; }                                             \
         read_frags(wsoff, KW, 2, 0); mfma_group(1);                                                   \
         if (x_live) { x_piece((KW) * 2 < 4 ? (KW) * 2 : 4); ++cnt; }                                  \
         read_frags(wsoff, KW, 3, 1); mfma_group(0);                                                   \
         if ((KW) < 2 && x_live) { x_piece((KW) * 2 + 1); ++cnt; }                                     \
+        if constexpr (PF) {                                                                           \
+            if (!(LASTSTEP)) {                                                                        \
+                /* kk = 0 of the next k-step: same weight slot (chunks 0/1), next tap of the patch ring */ \
+                constexpr int NKW = (KW) == 2 ? 0 : (KW) + 1;                                         \
+                const int nkh = (KW) == 2 ? (kh == 2 ? 0 : kh + 1) : kh;                              \
+                const int nxs = (KW) == 2 ? (cx_slot == NXS - 1 ? 0 : cx_slot + 1) * XSLOT : xsoff;   \
+                _Pragma("unroll") for (int i = 0; i < MP; ++i)                                        \
+                    bbase[i] = ((tapmask[i] >> (nkh * 3 + NKW)) & 1u) ? nxs + brow[NKW][i] : OFF_Z + (brow[NKW][i] & 128); \
+                read_frags(wsoff, NKW, 0, 0);                                                         \
+            }                                                                                         \
+        }                                                                                             \
         mfma_group(1);                                                                                \
         if ((KW) == 2 && x_live) advance_x();                                                         \
-        if (w_live) advance_w();                                                                      \
+        if (wfire) advance_w();                                                                       \
         last_cnt = cnt;                                                                               \
         if (FIRST) store_params();                                                                    \
         cw_slot = cw_slot == NWS - 1 ? 0 : cw_slot + 1;                                               \
@@ -429,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
                 ROWS_STEP(2, false, cb == cpt - 1 && kh == 2);
             }
         }
+#undef ROWS_WAIT
 #undef ROWS_STEP
         if (ct == t0) stamp(p.stamps, 4);
 
@@ -438,14 +503,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     stamp(p.stamps, 6);
 }
 
-template <int TC, int WP, int WC>
+template <int TC, int WP, int WC, bool PF>
 static hipError_t launch_rows_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + 255) / 256;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
     const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 10 * TC * 4;
     static bool attr_set[64] = {};
-    auto kern = conv3x3_rows_kernel<TC, WP, WC>;
+    auto kern = conv3x3_rows_kernel<TC, WP, WC, PF>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -473,8 +538,13 @@ bool conv3x3_rows_eligible(const ConvParams& p) {
 
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
-    if (p.Cout > 64) return launch_rows_cfg<128, 4, 2>(p, stream);
-    return launch_rows_cfg<64, 8, 1>(p, stream);
+    // dbg bit 2: the pre-prefetch k-step (A/B runs, bit-identical results)
+    if (p.dbg & 2) {
+        if (p.Cout > 64) return launch_rows_cfg<128, 4, 2, false>(p, stream);
+        return launch_rows_cfg<64, 8, 1, false>(p, stream);
+    }
+    if (p.Cout > 64) return launch_rows_cfg<128, 4, 2, true>(p, stream);
+    return launch_rows_cfg<64, 8, 1, true>(p, stream);
 }
 
 }  // namespace frp

@@ -347,7 +347,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
 
 int parse_net(frp_handle* h, const unsigned char* blob, size_t bytes, uint64_t off, uint32_t n_ops, uint32_t n_bufs,
               uint32_t in_buf, uint32_t in_ch, uint64_t data_bytes, Net& net) {
-    if (off + (uint64_t)n_ops * sizeof(frp_conv_op) > bytes) return fail(h, FRP_ERR_BLOB, "op table out of range");
+    if (off > bytes || n_ops > (bytes - off) / sizeof(frp_conv_op)) return fail(h, FRP_ERR_BLOB, "op table out of range");
     if (n_bufs == 0 || n_bufs > 4096 || in_buf >= n_bufs) return fail(h, FRP_ERR_BLOB, "bad buffer count");
     for (DevBuf& b : net.bufs) release(b);
     net.ops.resize(n_ops);
@@ -358,8 +358,9 @@ int parse_net(frp_handle* h, const unsigned char* blob, size_t bytes, uint64_t o
     net.bufs.assign(n_bufs, DevBuf());
     for (const frp_conv_op& op : net.ops) {
         if (op.in_buf < 0 || op.in_buf >= (int)n_bufs || op.out_buf < 0 || op.out_buf >= (int)n_bufs ||
-            op.res_buf >= (int)n_bufs || op.in_buf == op.out_buf || op.res_buf == op.out_buf)
+            op.res_buf >= (int)n_bufs || op.res_buf < -1 || op.in_buf == op.out_buf || op.res_buf == op.out_buf)
             return fail(h, FRP_ERR_BLOB, "op buffer id out of range");
+        if ((op.flags & FRP_FLAG_RES_UP2) && op.res_buf < 0) return fail(h, FRP_ERR_BLOB, "upsampled residual without a residual buffer");
         if (!(op.ksize == 1 || op.ksize == 3) || !(op.stride == 1 || op.stride == 2) || op.cin < 8 || (op.cin & 7) ||
             op.cout < 4 || (op.cout & 3) || op.act < 0 || op.act > 2)
             return fail(h, FRP_ERR_BLOB, "op shape not supported");
@@ -963,10 +964,14 @@ int frp_synchronize(frp_handle* h) {
     return FRP_OK;
 }
 
-int frp_fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts, float* emb,
-                      int32_t* match_idx, float* match_cos) {
+int frp_fetch_results(frp_handle* h, int32_t B, int32_t max_faces, float* boxes, float* kps, float* scores, int32_t* counts,
+                      float* emb, int32_t* match_idx, float* match_cos) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    // the caller sized its buffers for B x max_faces: refuse when another thread's call on this handle changed
+    // the shape of the results in between (checked under the handle mutex)
+    if (B != h->last_B || max_faces != h->last_K)
+        return fail(h, FRP_ERR_INVALID, "fetch_results: buffers sized for another batch (results were replaced by a later call)");
     return fetch_results(h, boxes, kps, scores, counts, emb, match_idx, match_cos);
 }
 
@@ -1001,10 +1006,11 @@ int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t 
     return FRP_OK;
 }
 
-int frp_detect_resident(frp_handle* h, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
+int frp_detect_resident(frp_handle* h, int32_t B, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
                         uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    if (B != h->rB) return fail(h, FRP_ERR_INVALID, "detect_resident: buffers sized for another resident batch");
     FRPCHK(select_det_source(h, det_h, det_w));
     FRPCHK(run_detect(h, max_faces, det_thresh, nms_iou, flags));
     const int B = h->rB;
@@ -1033,12 +1039,13 @@ int frp_get_det_source(frp_handle* h, uint8_t* out, int64_t out_bytes, int32_t* 
     return FRP_OK;
 }
 
-int frp_finish_faces(frp_handle* h, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
+int frp_finish_faces(frp_handle* h, int32_t B_in, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
                      int32_t max_faces, uint32_t flags, float* emb, int32_t* match_idx, float* match_cos) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
     if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
+    if (B_in != h->rB) return fail(h, FRP_ERR_INVALID, "finish_faces: face list sized for another resident batch");
     if (!kps || !counts || max_faces <= 0 || max_faces > FRP_MAX_FACES_CAP) return fail(h, FRP_ERR_INVALID, "bad face list");
     const int B = h->rB, K = max_faces;
     int n = 0;
@@ -1254,10 +1261,12 @@ int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* i
     return FRP_OK;
 }
 
-int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all) {
+int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all, int64_t n_cols) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (!cos_all) return fail(h, FRP_ERR_INVALID, "null output");
+    // cos_all holds M x n_cols floats: the gallery may have grown since the caller read its size
+    if (n_cols != h->g_rows) return fail(h, FRP_ERR_INVALID, "match_scores: output sized for another gallery size");
     return match_common(h, q, M, cos_all, nullptr, nullptr);
 }
 
@@ -1317,7 +1326,9 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
                    int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg, uint64_t* stamps_out) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    if (!ms_avg || iters <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(h, FRP_ERR_INVALID, "bad bench arguments");
+    if (!ms_avg || iters <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !(ksize == 1 || ksize == 3) ||
+        !(stride == 1 || stride == 2))
+        return fail(h, FRP_ERR_INVALID, "bad bench arguments");
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, wn = (size_t)Cout * ksize * ksize * Cin, on = (size_t)N * Ho * Wo * Cout;

@@ -45,6 +45,7 @@ BATCH_WORKERS = int(os.getenv("FACE_BATCH_WORKERS", "4"))             # :46 (bat
 BACKUP_DIR = Path(os.getenv("FACE_BACKUP_DIR", "data/backups"))       # :47
 DET_THRESH = float(os.getenv("FRP_DET_THRESH", "0.5"))
 NMS_IOU = float(os.getenv("FRP_NMS_IOU", "0.4"))
+CLUSTER_TILE = 64          # candidate seeds scored per gallery pass in cluster_faces
 MAX_FACES_ENCODE = int(os.getenv("FRP_MAX_FACES", "64"))
 
 _METRIC_KEYS = ("total_encodings", "total_comparisons", "cache_hits", "cache_misses",
@@ -317,41 +318,47 @@ class FaceService:
     def _distances(self, encoding, names: Optional[List[str]] = None) -> Tuple[List[str], np.ndarray]:
         """names (dict order) and their distances to `encoding`: one device pass over the gallery."""
         G = self.ENCODINGS
-        targets = G.names() if names is None else [t for t in names if t in G]
-        if not targets:
-            return [], np.zeros((0,))
-        q = np.asarray(encoding, dtype=np.float32).reshape(1, -1)
-        cos = self._eng().match_scores(q)[0]
-        return targets, cos_to_distance(cos[G.rows_of(targets)])
+        with G.locked():           # names, device rows and the score row belong to ONE gallery state
+            targets = G.names() if names is None else [t for t in names if t in G]
+            if not targets:
+                return [], np.zeros((0,))
+            q = np.asarray(encoding, dtype=np.float32).reshape(1, -1)
+            cos = self._eng().match_scores(q)[0]
+            return targets, cos_to_distance(cos[G.rows_of(targets)])
 
     # ------------------------------------------------------------------ store / delete (:344-390, :517-547)
     def store_face(self, target_name: str, encoding: np.ndarray) -> Dict[str, Any]:
         try:
             enc = np.asarray(encoding, dtype=np.float64).reshape(-1)
             is_dup, similar = False, None
-            if len(self.ENCODINGS):
-                names, d = self._distances(enc)
-                for n, dist in zip(names, d):          # first hit in dict order, as :353-364
-                    if n != target_name and dist < 0.3:
-                        is_dup, similar = True, n
-                        logger.warning("Potential duplicate: %s ~ %s (distance=%.3f)", target_name, n, dist)
-                        break
-            already = target_name in self.ENCODINGS
-            if not self._storage.store_embedding(target_name, enc.tolist()):
-                return {"success": False, "message": "Failed to store in database", "is_duplicate": is_dup}
-            self.ENCODINGS.put(target_name, enc)
-            try:
-                self._backup_encoding_atomic(target_name, enc.tolist())
-            except Exception as be:
-                logger.warning("Backup failed for %s: %s", target_name, be)
-            message = f"Face {'updated' if already else 'stored'} successfully for '{target_name}'"
-            if is_dup:
-                message += f" (Warning: Similar to '{similar}')"
-            return {"success": True, "message": message, "is_duplicate": is_dup,
-                    "similar_to": similar if is_dup else None, "was_update": already}
+            with self.ENCODINGS.locked():
+                return self._store_face_locked(target_name, enc, is_dup, similar)
         except Exception as e:
             logger.exception("Error storing face %s: %s", target_name, e)
             return {"success": False, "message": f"Error storing face: {str(e)}", "is_duplicate": False}
+
+    def _store_face_locked(self, target_name: str, enc: np.ndarray, is_dup: bool, similar) -> Dict[str, Any]:
+        """duplicate scan + insert against ONE gallery state (caller holds the gallery lock)"""
+        if len(self.ENCODINGS):
+            names, d = self._distances(enc)
+            for n, dist in zip(names, d):          # first hit in dict order, as :353-364
+                if n != target_name and dist < 0.3:
+                    is_dup, similar = True, n
+                    logger.warning("Potential duplicate: %s ~ %s (distance=%.3f)", target_name, n, dist)
+                    break
+        already = target_name in self.ENCODINGS
+        if not self._storage.store_embedding(target_name, enc.tolist()):
+            return {"success": False, "message": "Failed to store in database", "is_duplicate": is_dup}
+        self.ENCODINGS.put(target_name, enc)
+        try:
+            self._backup_encoding_atomic(target_name, enc.tolist())
+        except Exception as be:
+            logger.warning("Backup failed for %s: %s", target_name, be)
+        message = f"Face {'updated' if already else 'stored'} successfully for '{target_name}'"
+        if is_dup:
+            message += f" (Warning: Similar to '{similar}')"
+        return {"success": True, "message": message, "is_duplicate": is_dup,
+                "similar_to": similar if is_dup else None, "was_update": already}
 
     def delete_face(self, target_name: str) -> Dict[str, Any]:
         try:
@@ -409,12 +416,15 @@ class FaceService:
     def batch_compare_faces(self, test_encodings: List[np.ndarray], target_names: Optional[List[str]] = None):
         """:448-481 -- one device GEMM for all queries instead of a Python loop over them."""
         G = self.ENCODINGS
-        targets = G.names() if target_names is None else [t for t in target_names if t in G]
-        if not targets or len(test_encodings) == 0:
-            return [[] for _ in test_encodings]
+        if len(test_encodings) == 0:
+            return []
         try:
-            Q = np.stack([np.asarray(q, dtype=np.float32).reshape(-1) for q in test_encodings])
-            D = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(targets)])
+            with G.locked():
+                targets = G.names() if target_names is None else [t for t in target_names if t in G]
+                if not targets:
+                    return [[] for _ in test_encodings]
+                Q = np.stack([np.asarray(q, dtype=np.float32).reshape(-1) for q in test_encodings])
+                D = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(targets)])
         except Exception as e:
             logger.exception("Error in batch comparison: %s", e)
             return [[] for _ in test_encodings]
@@ -435,25 +445,35 @@ class FaceService:
     # ------------------------------------------------------------------ clustering / k-NN (:552-612)
     def cluster_faces(self, distance_threshold: float = 0.6) -> Dict[str, List[str]]:
         G = self.ENCODINGS
-        if len(G) < 2:
-            return {"cluster_0": G.names()}
-        names = G.names()
-        rows = G.rows_of(names)
-        emb = self._eng().gallery_get().astype(np.float32)[rows]
-        clusters: Dict[str, List[str]] = {}
-        assigned = np.zeros(len(names), dtype=bool)
-        cid = 0
-        for i, name in enumerate(names):           # greedy seed order = dict order, as the reference
-            if assigned[i]:
-                continue
-            d = cos_to_distance(self._eng().match_scores(emb[i:i + 1])[0][rows])
-            take = (~assigned) & (d <= distance_threshold)
-            take[i] = True
-            members = [name] + [names[j] for j in np.nonzero(take)[0] if j != i]
-            assigned |= take
-            clusters[f"cluster_{cid}"] = members
-            cid += 1
-        return clusters
+        with G.locked():
+            if len(G) < 2:
+                return {"cluster_0": G.names()}
+            names = G.names()
+            rows = G.rows_of(names)
+            emb = self._eng().gallery_get().astype(np.float32)[rows]
+            clusters: Dict[str, List[str]] = {}
+            assigned = np.zeros(len(names), dtype=bool)
+            cid = 0
+            # N x N on the device: the seeds of one greedy sweep are not known up front (a member never becomes
+            # a seed), so score rows are produced in tiles of CLUSTER_TILE candidate seeds per gallery pass
+            # (one frp_match_scores GEMM each) instead of one pass per seed
+            tile_rows: Dict[int, int] = {}
+            tile = None
+            for i, name in enumerate(names):           # greedy seed order = dict order, as the reference
+                if assigned[i]:
+                    continue
+                if i not in tile_rows:                 # next tile: the first CLUSTER_TILE unassigned names from i on
+                    cand = [j for j in range(i, len(names)) if not assigned[j]][:CLUSTER_TILE]
+                    tile_rows = {j: t for t, j in enumerate(cand)}
+                    tile = cos_to_distance(self._eng().match_scores(emb[cand])[:, rows])
+                d = tile[tile_rows[i]]
+                take = (~assigned) & (d <= distance_threshold)
+                take[i] = True
+                members = [name] + [names[j] for j in np.nonzero(take)[0] if j != i]
+                assigned |= take
+                clusters[f"cluster_{cid}"] = members
+                cid += 1
+            return clusters
 
     def find_k_nearest(self, test_encoding: np.ndarray, k: int = 5) -> List[Dict[str, Any]]:
         """face_service.py:590-612 with the distance pass AND the k-selection on the device (ties: the
@@ -470,9 +490,10 @@ class FaceService:
             pairs = [(targets[int(i)], float(distances[int(i)])) for i in idx]
         else:
             q = np.asarray(test_encoding, dtype=np.float32).reshape(1, -1)
-            rows, cos = self._eng().match(q, topk=k)
-            rows, cos = np.atleast_2d(rows)[0], np.atleast_2d(cos)[0]
-            pairs = [(self.ENCODINGS.name_of_row(int(r)), float(cos_to_distance(float(c)))) for r, c in zip(rows, cos) if r >= 0]
+            with self.ENCODINGS.locked():      # rows -> names against the gallery state the match saw
+                rows, cos = self._eng().match(q, topk=k)
+                rows, cos = np.atleast_2d(rows)[0], np.atleast_2d(cos)[0]
+                pairs = [(self.ENCODINGS.name_of_row(int(r)), float(cos_to_distance(float(c)))) for r, c in zip(rows, cos) if r >= 0]
         return [{"target": t, "distance": d, "confidence": confidence_level(d),
                  "confidence_score": calibrate_confidence(d)} for t, d in pairs]
 
@@ -486,15 +507,22 @@ class FaceService:
         tolerance and `threshold` (the reference's exact loop semantics, camera.py:246-256: a face
         can hit several near-duplicate identities), ascending by distance, under "matches"."""
         tol = self.tolerance if threshold is None else min(self.tolerance, threshold)   # camera.py:250
-        have_gallery = len(self.ENCODINGS) > 0
-        out = self._eng().process_frames(frames_bgr, max_faces=max_faces,
-                                         det_thresh=DET_THRESH if det_thresh is None else det_thresh, nms_iou=NMS_IOU,
-                                         flags=0 if have_gallery else native.FLAG_NO_MATCH)
-        all_d = names = None
-        if all_matches and have_gallery and int(out["counts"].sum()) > 0:
-            Q = np.concatenate([out["emb"][b, :int(c)] for b, c in enumerate(out["counts"])])
-            names = self.ENCODINGS.names()
-            all_d = cos_to_distance(self._eng().match_scores(Q)[:, self.ENCODINGS.rows_of(names)])
+        G = self.ENCODINGS
+        # The device returns gallery ROW indices; store/delete move rows (swap-remove).  The lock is held over the
+        # device call and the row -> name snapshot, so a concurrent delete can neither mis-attribute a face to the
+        # identity that was moved into its row nor shrink the table under the lookup.
+        with G.locked():
+            have_gallery = len(G) > 0
+            out = self._eng().process_frames(frames_bgr, max_faces=max_faces,
+                                             det_thresh=DET_THRESH if det_thresh is None else det_thresh, nms_iou=NMS_IOU,
+                                             flags=0 if have_gallery else native.FLAG_NO_MATCH)
+            n_gallery = len(G)
+            row_names = {int(r): G.name_of_row(int(r)) for r in np.unique(out["match_idx"]) if r >= 0}
+            all_d = names = None
+            if all_matches and have_gallery and int(out["counts"].sum()) > 0:
+                Q = np.concatenate([out["emb"][b, :int(c)] for b, c in enumerate(out["counts"])])
+                names = G.names()
+                all_d = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(names)])
         f_idx = 0
         result = []
         n_total = 0
@@ -506,7 +534,7 @@ class FaceService:
                 d = float(cos_to_distance(cos)) if row >= 0 else None
                 faces.append({"bbox": out["boxes"][b, k].tolist(), "kps": out["kps"][b, k].tolist(),
                               "score": float(out["scores"][b, k]), "embedding": out["emb"][b, k],
-                              "target": self.ENCODINGS.name_of_row(row) if row >= 0 else None,
+                              "target": row_names.get(row) if row >= 0 else None,
                               "distance": d, "cosine": cos if row >= 0 else None,
                               "confidence": confidence_level(d) if d is not None else None,
                               "match": bool(d is not None and d <= tol)})
@@ -523,7 +551,7 @@ class FaceService:
             result.append(faces)
         with self._metrics_lock:
             self._metrics["total_encodings"] += n_total
-            self._metrics["total_comparisons"] += n_total * len(self.ENCODINGS)
+            self._metrics["total_comparisons"] += n_total * n_gallery
         return result
 
     def process_frame(self, frame_bgr_or_path, metadata: Optional[Dict[str, Any]] = None):

@@ -38,6 +38,13 @@ class Gallery(Mapping):
             row = self._rows[name]
             return self._eng().gallery_get(row, 1)[0].astype(np.float64).tolist()
 
+    def locked(self):
+        """The lock every update takes.  A reader that resolves device row indices to names (match ->
+        name_of_row / rows_of) holds it across the device call AND the lookup: `remove` is a swap-remove, so a
+        delete between the two would attribute a face to the identity that was moved into that row (the
+        reference builds names and matrix in one call, face_service.py:403-411, and cannot mis-attribute)."""
+        return self._lock
+
     # ---- updates
     def names(self) -> List[str]:
         return list(self._rows.keys())

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
@@ -83,7 +84,7 @@ def load_library() -> C.CDLL:
     lib.frp_process_frames.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.frp_upload_frames.argtypes = [vp, vp, i32, i32, i32, i64]
     lib.frp_process_resident.argtypes = [vp, i32, f32, f32, u32]
-    lib.frp_fetch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.frp_fetch_results.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.frp_synchronize.argtypes = [vp]
     lib.frp_host_alloc.argtypes = [vp, C.c_size_t]
     lib.frp_host_alloc.restype = vp
@@ -92,16 +93,16 @@ def load_library() -> C.CDLL:
     lib.frp_upload_frames_async.argtypes = [vp, vp, i32, i32, i32, i64]
     lib.frp_swap_frames.argtypes = [vp]
     lib.frp_detect.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp]
-    lib.frp_detect_resident.argtypes = [vp, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
+    lib.frp_detect_resident.argtypes = [vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_get_det_source.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
-    lib.frp_finish_faces.argtypes = [vp, vp, vp, vp, vp, i32, u32, vp, vp, vp]
+    lib.frp_finish_faces.argtypes = [vp, i32, vp, vp, vp, vp, i32, u32, vp, vp, vp]
     lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.frp_decode_heads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_align.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
     lib.frp_embed_aligned.argtypes = [vp, vp, i32, vp]
     lib.frp_embed_faces.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
     lib.frp_match.argtypes = [vp, vp, i32, i32, vp, vp]
-    lib.frp_match_scores.argtypes = [vp, vp, i32, vp]
+    lib.frp_match_scores.argtypes = [vp, vp, i32, vp, i64]
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
     lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
@@ -132,11 +133,19 @@ class Engine:
         self._h = h
         self.device = device
         self.max_faces = max_faces
+        # Multi-call sequences (upload -> process -> fetch, the pyramid) leave state on the handle between calls:
+        # threads sharing one Engine take this lock around a whole sequence (`with eng.sequence(): ...`).  The
+        # C side additionally checks every caller-sized buffer against the handle's state under its own mutex.
+        self._seq = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.frp_destroy(self._h)
             self._h = C.c_void_p()
+
+    def sequence(self):
+        """lock held around a multi-call sequence on a shared Engine"""
+        return self._seq
 
     def __del__(self):
         try:
@@ -244,7 +253,7 @@ class Engine:
     def fetch_results(self) -> dict:
         B = self._resident[0]
         o = self._alloc(B, self._last_k)
-        self._chk(self._lib.frp_fetch_results(self._h, _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]),
+        self._chk(self._lib.frp_fetch_results(self._h, B, self._last_k, _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]),
                                               _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
         return o
 
@@ -264,7 +273,7 @@ class Engine:
         B = self._resident[0]
         o = self._alloc(B, max_faces)
         anchor = np.full((B, max_faces), -1, np.int32)
-        self._chk(self._lib.frp_detect_resident(self._h, det_hw[0], det_hw[1], max_faces, det_thresh, nms_iou, flags,
+        self._chk(self._lib.frp_detect_resident(self._h, B, det_hw[0], det_hw[1], max_faces, det_thresh, nms_iou, flags,
                                                 _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]), _ptr(anchor)))
         o["anchor_idx"] = anchor
         self._det_batch = B
@@ -286,7 +295,7 @@ class Engine:
         scores = np.ascontiguousarray(scores, np.float32).reshape(B, max_faces)
         counts = np.ascontiguousarray(counts, np.int32).reshape(B)
         o = self._alloc(B, max_faces)
-        self._chk(self._lib.frp_finish_faces(self._h, _ptr(boxes), _ptr(kps), _ptr(scores), _ptr(counts), max_faces, flags,
+        self._chk(self._lib.frp_finish_faces(self._h, B, _ptr(boxes), _ptr(kps), _ptr(scores), _ptr(counts), max_faces, flags,
                                              _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
         o.update(boxes=boxes, kps=kps, scores=scores, counts=counts)
         return o
@@ -297,14 +306,15 @@ class Engine:
         (pyramid.merge_scales), then align / embed / match from the full-resolution frames."""
         from . import pyramid
         frames, B, H, W, _ = self._frames(frames)
-        self.upload_frames(frames)
-        per = []
-        for s in scales:
-            hw = pyramid.scaled_size(H, W, s)
-            per.append((hw, self.detect_resident(hw, max_faces=per_scale, det_thresh=det_thresh, nms_iou=nms_iou,
-                                                 flags=flags & ~FLAG_FORCED_K)))
-        boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), max_faces, nms_iou)
-        return self.finish_faces(boxes, kps, scores, counts, max_faces, flags & (FLAG_RGB | FLAG_NO_MATCH))
+        with self._seq:
+            self.upload_frames(frames)
+            per = []
+            for s in scales:
+                hw = pyramid.scaled_size(H, W, s)
+                per.append((hw, self.detect_resident(hw, max_faces=per_scale, det_thresh=det_thresh, nms_iou=nms_iou,
+                                                     flags=flags & ~FLAG_FORCED_K)))
+            boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), max_faces, nms_iou)
+            return self.finish_faces(boxes, kps, scores, counts, max_faces, flags & (FLAG_RGB | FLAG_NO_MATCH))
 
     def head_maps(self):
         """fp16 head maps [B,H_l,W_l,32] of the last detect/process call, strides 8/16/32."""
@@ -359,9 +369,18 @@ class Engine:
         return idx, cos
 
     def match_scores(self, q: np.ndarray) -> np.ndarray:
+        """all cosines [M, N].  The output is sized from gallery_size(); the library re-checks that size under
+        its mutex and refuses (nothing written) if a concurrent update changed it -- then size again and retry."""
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, EMB_DIM)
-        out = np.empty((q.shape[0], self.gallery_size()), np.float32)
-        self._chk(self._lib.frp_match_scores(self._h, _ptr(q), q.shape[0], _ptr(out)))
+        for _ in range(8):
+            n = self.gallery_size()
+            out = np.empty((q.shape[0], n), np.float32)
+            rc = self._lib.frp_match_scores(self._h, _ptr(q), q.shape[0], _ptr(out), n)
+            if rc == 0:
+                return out
+            if self.gallery_size() == n:
+                break
+        self._chk(rc)
         return out
 
     def conv2d(self, x, w, bias, stride=1, act=0, slope=None, res=None, flags=0):

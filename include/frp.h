@@ -133,7 +133,9 @@ int frp_process_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, 
  * region starts with inputs already on the device): upload once, process many, fetch. */
 int frp_upload_frames(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride);
 int frp_process_resident(frp_handle* h, int32_t max_faces, float det_thresh, float nms_iou, uint32_t flags);
-int frp_fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts,
+/* B, max_faces: the shape the caller's buffers were sized for; FRP_ERR_INVALID when the handle's last results have
+ * another shape (a concurrent caller replaced them) -- nothing is written then */
+int frp_fetch_results(frp_handle* h, int32_t B, int32_t max_faces, float* boxes, float* kps, float* scores, int32_t* counts,
                       float* emb, int32_t* match_idx, float* match_cos);
 int frp_synchronize(frp_handle* h);
 
@@ -158,11 +160,12 @@ int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t 
  * landmarks come back in the coordinates of the resized image.  The caller merges the scales
  * (pyramid.merge_scales) and hands the merged landmarks to frp_finish_faces, which aligns from the
  * full-resolution resident frames, embeds and matches.  counts[b] <= max_faces faces per frame. */
-int frp_detect_resident(frp_handle* h, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
+int frp_detect_resident(frp_handle* h, int32_t B, int32_t det_h, int32_t det_w, int32_t max_faces, float det_thresh, float nms_iou,
                         uint32_t flags, float* boxes, float* kps, float* scores, int32_t* counts, int32_t* anchor_idx);
 /* the u8 frames the detector last read (the resident frames or their resize), [B, hs, ws, 3] (parity tests) */
 int frp_get_det_source(frp_handle* h, uint8_t* out, int64_t out_bytes, int32_t* hs, int32_t* ws);
-int frp_finish_faces(frp_handle* h, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
+/* B: the resident batch the face list and the output buffers were sized for (checked under the handle mutex) */
+int frp_finish_faces(frp_handle* h, int32_t B, const float* boxes, const float* kps, const float* scores, const int32_t* counts,
                      int32_t max_faces, uint32_t flags, float* emb, int32_t* match_idx, float* match_cos);
 
 /* raw detector head maps of the last detect/process call, per stride level 0..2:
@@ -186,7 +189,9 @@ int frp_embed_faces(frp_handle* h, const uint8_t* bgr, int32_t H, int32_t W, int
  * -> face_recognition.face_distance + argmin / argpartition (face_service.py:410,599-603) */
 int frp_match(frp_handle* h, const float* q, int32_t M, int32_t topk, int32_t* idx, float* cos);
 /* all cosines [M x N] (the N-dict compat path of compare_faces, face_service.py:409-432) */
-int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all);
+/* n_cols: the gallery size cos_all was sized for; FRP_ERR_INVALID (nothing written) when the gallery has another size
+ * by the time the call holds the handle -- re-read frp_gallery_size and retry */
+int frp_match_scores(frp_handle* h, const float* q, int32_t M, float* cos_all, int64_t n_cols);
 
 /* one convolution through the MFMA kernel on host tensors (kernel parity tests):
  * x [N,H,W,Cin] fp16, w [Cout][k][k][Cin] fp16, bias fp32 [Cout] or [9][Cout], out fp16 or fp32 */
