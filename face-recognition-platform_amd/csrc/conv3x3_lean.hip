@@ -1,0 +1,449 @@
+// K2b (second generation): 3x3 stride-1 convolution with ROW PATCHES and a STATIC k-loop.
+//
+// Same data path as conv3x3_rows.hip (row patches for the pixel operand, per-tap weight stages, LDS-DMA rings that
+// run across tiles, zero padding decided at fragment-read time, identical accumulation order and epilogue - the two
+// kernels agree bit for bit), but the k-loop carries no run-time bookkeeping:
+//
+//   * the nine taps of a 64-channel block are one fully unrolled body.  A tile consumes 9*cpt weight stages and
+//     3*cpt row patches - multiples of the ring depth 3 - so every ring slot, tap index and vmcnt count inside the
+//     body is a compile-time constant (the first generation advanced cursors, slot counters and "live" flags with
+//     ~80 scalar instructions and a dozen branches per k-step: measured 17 % of the loop against the same
+//     MFMA / ds_read / DMA stream without them, tools/kstep_lab.py);
+//   * the DMA stream never stops or branches: past the last tile of a workgroup the per-lane source offsets are
+//     out of range, the hardware range check writes zeros into slots nobody reads any more;
+//   * weight pieces take the (channel block, tap) part of their source address in the SGPR offset operand of
+//     buffer_load ... lds (not range-checked, always inside the row), so their VGPR offset changes once per tile.
+//
+// Replaces the same reference calls as conv_mfma.hip (face_recognition.face_locations / face_encodings,
+// backend/app/routes/camera.py:232,237, backend/app/services/face_service.py:156,179).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "frp_internal.h"
+#include "conv_common.h"
+
+namespace frp {
+
+// one LDS-DMA piece with a scalar byte offset added to the source address (not part of the range check)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
+}
+
+template <int TC, int WP, int WC>
+__global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    constexpr int TP = 256, NW = 8;
+    constexpr int XROWS = 264;                // 33 groups of 8 rows; rows 0..257 are read
+    constexpr int XSLOT = XROWS * 128;        // 33,792 B (a multiple of 256)
+    constexpr int WSLOT = TC * 128;
+    constexpr int WI = TC / 8 / NW;           // weight DMA pieces per wave per k-step (2 or 1)
+    constexpr int MP = TP / WP / 32, MC = TC / WC / 32;
+    constexpr int OFF_W = 3 * XSLOT;
+    constexpr int OFF_Z = OFF_W + 3 * WSLOT;  // 256 zero bytes (256-aligned)
+    constexpr int OFF_PAR = OFF_Z + 256;
+    static_assert(WP * WC == NW && (WI == 1 || WI == 2) && MP * MC <= 4 && (OFF_Z & 255) == 0, "layout");
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    const int n_tiles = p.n_ptiles * p.n_ctiles;
+    // XCD-interleaved tile walk (see conv3x3_rows.hip)
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = per;
+    } else {
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
+    if (t0 >= t1) return;
+    const int cpt = p.Cin >> 6;                // 64-channel blocks
+    const int cin2 = p.Cin * 2;                // bytes per pixel = bytes per tap in a weight row
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---------------- DMA lane geometry (as conv3x3_rows.hip): a piece fills 8 LDS rows x 128 B; lane -> row lane/8,
+    // chunk position lane%8 holding logical chunk pos ^ ((row>>1)&7) (source-side swizzle)
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+    const int lchunk32 = (lane & 7) ^ (lane >> 4);
+    const int khpitch = p.W * cin2;            // bytes per image row
+    constexpr int DEAD = (int)0x80000000;      // per-lane offset that stays out of range whatever is added to it
+
+    // Source descriptors of one tile.  X: per-lane byte offset of (patch row, chunk) for kh = 0, cb = 0 (pieces 0..3
+    // and the 33rd row group); W: per-lane byte offset of (cout row, chunk) at tap 0, cb 0 - or DEAD.
+    struct Desc { int xg, xg32; unsigned woff[WI]; };
+    auto make_desc = [&](int tile, Desc& d) {
+        if (tile >= t1) {
+            d.xg = d.xg32 = DEAD;
+#pragma unroll
+            for (int i = 0; i < WI; ++i) d.woff[i] = CONV_OOB;
+            return;
+        }
+        const int pt = tile / p.n_ctiles;
+        const int m0i = pt * TP, c0i = (tile - pt * p.n_ctiles) * TC;
+        d.xg = (m0i - p.W - 1 + wave * 8 + lrow) * cin2 + lchunk * 16;
+        d.xg32 = (m0i - p.W - 1 + 256 + lrow) * cin2 + lchunk32 * 16;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int co = c0i + (i * NW + wave) * 8 + lrow;
+            d.woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
+        }
+    };
+    // piece q (0..3: row group wave + 8q, 4: group 32) of patch (cb byte offset cbs, kernel row kh) into ring slot `slot`
+    auto x_piece = [&](const Desc& d, int q, int kh, int cbs, int slot) {
+        const int rs = kh * khpitch + cbs;
+        if (q < 4) dma16(xrsrc, smem + slot * XSLOT + (wave + 8 * q) * 1024, (unsigned)(d.xg + rs + q * 64 * cin2));
+        else dma16(xrsrc, smem + slot * XSLOT + 32 * 1024, (unsigned)(d.xg32 + rs));
+    };
+    // weight stage (tap, cb byte offset cbs) into ring slot `slot`: this wave's WI pieces
+    auto w_stage = [&](const Desc& d, int tap, int cbs, int slot) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            dma16s(wrsrc, smem + OFF_W + slot * WSLOT + (i * NW + wave) * 1024, d.woff[i], tap * cin2 + cbs);
+    };
+
+    // ---------------- consumer geometry
+    const int wave_p = wave / WC, wave_c = wave - wave_p * WC;
+    const int prow0 = wave_p * (TP / WP), crow0 = wave_c * (TC / WC);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    // B fragment addressing: pixel row prow0 + 32i + fr of the tile reads patch row (that + kw), chunk 2kk + fh at
+    // 16-byte position (2kk + fh) ^ ((row >> 1) & 7).  pv[kw][i] = row * 128 + ((fh ^ ((row>>1)&7)) << 4) is the kk = 0
+    // address inside a patch slot, zv[kw][i] the same bank offset inside the 256-byte zero block (a lane whose tap lies
+    // outside the image reads zeros there without adding bank conflicts); kk flips address bits 5..6 (xor, not add,
+    // so it cannot ride in the instruction's immediate offset).
+    int pv[3][MP], zv[3][MP];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int row = prow0 + i * 32 + fr + kw;
+            const int bx = (fh ^ ((row >> 1) & 7)) << 4;
+            pv[kw][i] = row * 128 + bx;
+            zv[kw][i] = OFF_Z + ((row * 128) & 128) + bx;
+        }
+    int aoff[MC][4];                            // A fragment offsets inside a weight stage (+ OFF_W)
+#pragma unroll
+    for (int j = 0; j < MC; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) aoff[j][kk] = OFF_W + lds_off(crow0 + j * 32 + fr, 2 * kk + fh);
+
+    floatx16 acc[MP][MC];
+    half8 bf[2][MP], af[2][MC];
+    int bbase[MP];                              // per k-step: kk = 0 address of this lane's B rows (patch or zero block)
+    auto read_frags = [&](int wslot, int kw, int kk, int S) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+            bf[S][i] = *reinterpret_cast<const half8*>(smem + (bbase[i] ^ (kk << 5)));
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+            af[S][j] = *reinterpret_cast<const half8*>(smem + wslot * WSLOT + aoff[j][kk]);
+    };
+    auto mfma_group = [&](int S) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[S][j], bf[S][i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---------------- per-tile epilogue parameters in LDS (see conv_mfma.hip)
+    float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
+    float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
+    constexpr int PPT = (9 * TC + NW * 64 - 1) / (NW * 64);
+    float pb[PPT], ps = 0.f;
+    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
+    auto fetch_params = [&](int tile) {
+        const int c0p = (tile % p.n_ctiles) * TC;
+        const int nb = (border ? 9 : 1) * TC;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            const int cls = idx / TC, co = c0p + (idx - cls * TC);
+            pb[q] = (idx < nb && co < p.Cout) ? p.bias[(long)cls * p.Cout + co] : 0.f;
+        }
+        if (p.act == FRP_ACT_PRELU && t < TC) ps = (c0p + t < p.Cout) ? p.slope[c0p + t] : 0.f;
+    };
+    auto store_params = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            if (idx < 9 * TC) lds_bias[idx] = pb[q];
+        }
+        if (t < TC) lds_slope[t] = ps;
+    };
+
+    // ---------------- prologue: zero block; row patches (0,0), (0,1) and weight stages tap 0, 1 of the first tile
+    stamp(p.stamps, 0);
+    if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
+    __syncthreads();
+    Desc cur, nt;
+    make_desc(t0, cur);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) x_piece(cur, q, r, 0, r);
+        w_stage(cur, r, 0, r);
+    }
+    const bool out32 = p.flags & FRP_FLAG_OUT_F32;
+    const bool up2 = p.flags & FRP_FLAG_RES_UP2;
+    const bool has_res = p.res != nullptr;
+    const bool prelu = p.act == FRP_ACT_PRELU;
+    const bool relu = p.act == FRP_ACT_RELU;
+
+    // ---------------- epilogue of a tile (as conv3x3_rows.hip): bias / border-class bias from the LDS parameter cache,
+    // residual (requested one k-step early), activation in fp32, 16-byte fp16 stores after a half-wave exchange
+    // (fr_e / fh_e: copies of the lane coordinates made opaque per tile, so that the epilogue's address arithmetic is
+    // not hoisted to the top of the kernel and kept live - or spilled - across the whole k-loop)
+    uint4 rres[MP][MC][2];
+    int fr_e = fr, fh_e = fh;
+    auto issue_residual_loads = [&](int m0, int c0) __attribute__((always_inline)) {
+        const int fr = fr_e, fh = fh_e;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int mraw = m0 + prow0 + i * 32 + fr;
+            const int m = mraw < p.M ? mraw : 0;
+            long ridx = (long)m * p.Cout;
+            if (up2) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                    rres[i][j][q] = *reinterpret_cast<const uint4*>(p.res + ridx + (co < p.Cout ? co : 0));
+                }
+        }
+    };
+    auto epilogue_body = [&](auto FULL_T, int m0, int c0) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(FULL_T)::value;
+        const int fr = fr_e, fh = fh_e;
+        half4 r4[MP][MC][4];
+        bool mok[MP];
+        long obase[MP];
+        int cls[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int mraw = m0 + prow0 + i * 32 + fr;
+            mok[i] = FULL || mraw < p.M;
+            const int m = mok[i] ? mraw : 0;
+            cls[i] = 0;
+            if (border) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+            }
+            obase[i] = (long)m * p.Cout;
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < MC; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        uint4 rr = rres[i][j][q];
+                        swap_halves(rr.x, rr.z);
+                        swap_halves(rr.y, rr.w);
+                        union { unsigned u[2]; half4 h; } lo, hi;
+                        lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
+                        r4[i][j][2 * q] = lo.h;
+                        r4[i][j][2 * q + 1] = hi.h;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                floatx4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                    } else if (prelu) {
+                        const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
+                    }
+                }
+                if (out32) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                        if (FULL || (mok[i] && co < p.Cout))
+                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
+                    }
+                } else {
+                    union { half4 h; unsigned u[2]; } pk[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                        swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                        const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                        if (FULL || (mok[i] && co < p.Cout))
+                            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
+                                make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
+                    }
+                }
+            }
+        }
+    };
+    auto run_epilogue = [&](int m0, int c0) __attribute__((always_inline)) {
+        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}, m0, c0); else epilogue_body(std::false_type{}, m0, c0);
+    };
+
+    stamp(p.stamps, 1);
+    for (int ct = t0; ct < t1; ct += tstep) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int ptile = ct / p.n_ctiles;
+        const int m0 = ptile * TP;
+        const int c0 = (ct - ptile * p.n_ctiles) * TC;
+        // 9-bit tap validity of this lane's pixels (bit kh*3+kw), 0 for rows beyond M
+        unsigned tapmask[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int m = m0 + prow0 + i * 32 + fr;
+            unsigned mask = 0;
+            if (m < p.M) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                const unsigned ym = (oy > 0 ? 1u : 0u) | 2u | (oy < p.H - 1 ? 4u : 0u);
+                const unsigned xm = (ox > 0 ? 1u : 0u) | 2u | (ox < p.W - 1 ? 4u : 0u);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) mask |= ((ym >> d) & 1u) ? (xm << (3 * d)) : 0u;
+            }
+            tapmask[i] = mask;
+        }
+        make_desc(ct + tstep, nt);             // the tile after this one (DEAD past the end)
+        asm volatile("" : "+v"(fr_e), "+v"(fh_e));
+        if (ct == t0) stamp(p.stamps, 2);
+
+        // One k-step, everything about it static: tap KH*3+KW reads weight slot tap % 3 and patch slot KH; it fires the
+        // weight stage two taps ahead and - spread over the three steps of a kernel row - the patch two rows ahead.
+        // `nx` = the descriptor of what lies beyond this channel block (the next block of this tile, the next tile,
+        // or nothing), `ncbs` its channel-block byte offset.
+#define LEAN_STEP(KH, KW)                                                                                       \
+    do {                                                                                                        \
+        constexpr int TAP = (KH) * 3 + (KW);                                                                    \
+        if (TAP == 0) { if (cb == 0) wait_vmcnt<0>(); else wait_vmcnt<WI + 1>(); }                              \
+        else if ((KW) == 0) wait_vmcnt<WI + 1>();                                                               \
+        else wait_vmcnt<WI + 2>();                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                          \
+            bbase[i] = ((tapmask[i] >> TAP) & 1u) ? (KH) * XSLOT + pv[KW][i] : zv[KW][i];                       \
+        if (TAP == 0 && cb == 0) fetch_params(ct);                                                              \
+        read_frags(TAP % 3, KW, 0, 0);                                                                          \
+        read_frags(TAP % 3, KW, 1, 1); mfma_group(0);                                                           \
+        if (TAP < 7) w_stage(cur, TAP + 2, cbs, (TAP + 2) % 3); else w_stage(nx, TAP - 7, ncbs, (TAP + 2) % 3); \
+        read_frags(TAP % 3, KW, 2, 0); mfma_group(1);                                                           \
+        if ((KH) == 0) x_piece(cur, (KW) * 2 < 4 ? (KW) * 2 : 4, 2, cbs, 2);                                    \
+        else x_piece(nx, (KW) * 2 < 4 ? (KW) * 2 : 4, (KH) - 1, ncbs, ((KH) + 2) % 3);                          \
+        read_frags(TAP % 3, KW, 3, 1); mfma_group(0);                                                           \
+        if ((KW) < 2) {                                                                                         \
+            if ((KH) == 0) x_piece(cur, (KW) * 2 + 1, 2, cbs, 2);                                               \
+            else x_piece(nx, (KW) * 2 + 1, (KH) - 1, ncbs, ((KH) + 2) % 3);                                     \
+        }                                                                                                       \
+        /* the residual of the tile is requested under the last MFMA group (fragment set 0 is dead by then) */   \
+        if (TAP == 8 && cb == cpt - 1 && has_res) issue_residual_loads(m0, c0);                                 \
+        mfma_group(1);                                                                                          \
+        if (TAP == 0 && cb == 0) store_params();                                                                \
+    } while (0)
+
+        for (int cb = 0; cb < cpt; ++cb) {
+            const int cbs = cb << 7;
+            const bool inner = cb + 1 < cpt;
+            Desc nx;
+            nx.xg = inner ? cur.xg : nt.xg;
+            nx.xg32 = inner ? cur.xg32 : nt.xg32;
+#pragma unroll
+            for (int i = 0; i < WI; ++i) nx.woff[i] = inner ? cur.woff[i] : nt.woff[i];
+            const int ncbs = inner ? cbs + 128 : 0;
+            // (opaque per iteration: keeps the 9 x MP slot-offset sums and the per-piece source offsets from being
+            // hoisted out of the loop and held - or spilled - in registers)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int i = 0; i < MP; ++i) asm volatile("" : "+v"(pv[kw][i]), "+v"(zv[kw][i]));
+            asm volatile("" : "+v"(cur.xg), "+v"(cur.xg32), "+v"(nx.xg), "+v"(nx.xg32));
+            LEAN_STEP(0, 0);
+            if (cb == 0 && ct == t0) stamp(p.stamps, 3);
+            LEAN_STEP(0, 1);
+            LEAN_STEP(0, 2);
+            LEAN_STEP(1, 0);
+            LEAN_STEP(1, 1);
+            LEAN_STEP(1, 2);
+            LEAN_STEP(2, 0);
+            LEAN_STEP(2, 1);
+            LEAN_STEP(2, 2);
+        }
+#undef LEAN_STEP
+        if (ct == t0) stamp(p.stamps, 4);
+
+        run_epilogue(m0, c0);
+        cur = nt;
+        if (ct == t0) stamp(p.stamps, 5);
+    }
+    stamp(p.stamps, 6);
+}
+
+template <int TC, int WP, int WC>
+static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
+    ConvParams p = p0;
+    p.n_ptiles = (p.M + 255) / 256;
+    p.n_ctiles = (p.Cout + TC - 1) / TC;
+    const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 10 * TC * 4;
+    static bool attr_set[64] = {};
+    auto kern = conv3x3_lean_kernel<TC, WP, WC>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    const int ncu = device_cu_count(dev);
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
+    if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
+    if (p.Cout > 64) return launch_lean_cfg<128, 4, 2>(p, stream);
+    return launch_lean_cfg<64, 8, 1>(p, stream);
+}
+
+}  // namespace frp

@@ -37,7 +37,9 @@ namespace frp {
 // holds chunks 2..7 (kk = 1..3) of step s and, in chunk positions 0..1, kk = 0 of step s+1 - the DMA source
 // address is per lane, so lanes carrying logical chunks 0/1 simply run their cursor one step ahead.  The pixel
 // side needs nothing: the row patches are resident two row steps ahead anyway.
-template <int TC, int WP, int WC, bool PF>
+// ABL: timing-only ablations for tools/conv_bench.py (results are wrong): 1 no MFMA, 2 no fragment reads, 4 no DMA,
+// 8 no barrier.
+template <int TC, int WP, int WC, bool PF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int TP = 256, NW = 8;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     };
     // piece q (0..3: group wave + 8q, 4: group 32) of the patch under the X cursor
     auto x_piece = [&](int q) {
+        if constexpr (ABL & 4) return;
         const int rs = x_kh * khpitch + (x_cb << 7);
         if (q < 4)
             dma16(xrsrc, smem + x_slot * XSLOT + (wave + 8 * q) * 1024, (unsigned)(xg + rs + q * 64 * rowpitch));
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         for (int i = 0; i < WI; ++i) voffN[i] = (w_live && woff[i] != CONV_OOB) ? woff[i] + kadd : CONV_OOB;
     };
     auto w_piece = [&](int i) {
+        if constexpr (ABL & 4) return;
         if constexpr (PF) {
             dma16(wrsrc, smem + OFF_W + w_slot * WSLOT + (i * NW + wave) * 1024, is0 ? voffN[i] : voffC[i]);
         } else {
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     half8 bf[2][MP], af[2][MC];
     int bbase[MP];                              // per k-step: patch row address or the zero block
     auto read_frags = [&](int wsoff, int kw, int kk, int S) {
+        if constexpr (ABL & 2) return;
 #pragma unroll
         for (int i = 0; i < MP; ++i)
             bf[S][i] = *reinterpret_cast<const half8*>(smem + bbase[i] + (bxor[kw][i] ^ (kk << 5)));
@@ -202,12 +207,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
             af[S][j] = *reinterpret_cast<const half8*>(smem + wsoff + aoff[j][kk]);
     };
     auto mfma_group = [&](int S) {
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < MP; ++i) asm volatile("" ::"v"(bf[S][i]));
+#pragma unroll
+            for (int j = 0; j < MC; ++j) asm volatile("" ::"v"(af[S][j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
             for (int j = 0; j < MC; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[S][j], bf[S][i], acc[i][j], 0, 0, 0);
     };
+    if constexpr (ABL & 2) {                   // fragments: anything finite, loaded once
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+#pragma unroll
+            for (int i = 0; i < MP; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[S][i][e] = (_Float16)(0.001f * (lane + e + i));
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[S][j][e] = (_Float16)(0.002f * (lane - e + j));
+        }
+    }
 
     // ---------------- per-tile epilogue parameters in LDS (see conv_mfma.hip)
     float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
         ROWS_WAIT();                                                                                  \
         /* PF: the prefetched fragments are in registers, so the slot they came from may be refilled */ \
         if constexpr (PF) wait_lgkmcnt0();                                                            \
-        __builtin_amdgcn_s_barrier();                                                                 \
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                       \
         const int xsoff = cx_slot * XSLOT;                                                            \
         const int wsoff = OFF_W + cw_slot * WSLOT;                                                    \
         if constexpr (!PF) {                                                                          \
@@ -503,14 +528,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(ConvParams p) {
     stamp(p.stamps, 6);
 }
 
-template <int TC, int WP, int WC, bool PF>
+template <int TC, int WP, int WC, bool PF, int ABL = 0>
 static hipError_t launch_rows_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + 255) / 256;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
     const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 10 * TC * 4;
     static bool attr_set[64] = {};
-    auto kern = conv3x3_rows_kernel<TC, WP, WC, PF>;
+    auto kern = conv3x3_rows_kernel<TC, WP, WC, PF, ABL>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -538,13 +563,30 @@ bool conv3x3_rows_eligible(const ConvParams& p) {
 
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
-    // dbg bit 2: the pre-prefetch k-step (A/B runs, bit-identical results)
+    // dbg bits 2..5: timing-only ablations of the 128-cout kernel (wrong results; conv_bench only)
+    if (p.Cout > 64) switch ((p.dbg >> 2) & 15) {
+        case 1: return launch_rows_cfg<128, 4, 2, false, 1>(p, stream);
+        case 2: return launch_rows_cfg<128, 4, 2, false, 2>(p, stream);
+        case 4: return launch_rows_cfg<128, 4, 2, false, 4>(p, stream);
+        case 8: return launch_rows_cfg<128, 4, 2, false, 8>(p, stream);
+        case 6: return launch_rows_cfg<128, 4, 2, false, 6>(p, stream);
+        case 14: return launch_rows_cfg<128, 4, 2, false, 14>(p, stream);
+        case 5: return launch_rows_cfg<128, 4, 2, false, 5>(p, stream);
+        case 13: return launch_rows_cfg<128, 4, 2, false, 13>(p, stream);
+        case 12: return launch_rows_cfg<128, 4, 2, false, 12>(p, stream);
+        case 10: return launch_rows_cfg<128, 4, 2, false, 10>(p, stream);
+        default: break;
+    }
+    // dbg bit 2 (value 2): the pre-prefetch k-step (A/B runs, bit-identical results)
     if (p.dbg & 2) {
         if (p.Cout > 64) return launch_rows_cfg<128, 4, 2, false>(p, stream);
         return launch_rows_cfg<64, 8, 1, false>(p, stream);
     }
-    if (p.Cout > 64) return launch_rows_cfg<128, 4, 2, true>(p, stream);
-    return launch_rows_cfg<64, 8, 1, true>(p, stream);
+    if (p.dbg & 64) {                              // first-generation kernel with the cross-barrier prefetch
+        if (p.Cout > 64) return launch_rows_cfg<128, 4, 2, true>(p, stream);
+        return launch_rows_cfg<64, 8, 1, true>(p, stream);
+    }
+    return launch_conv3x3_lean(p, stream);       // second generation: static k-loop (conv3x3_lean.hip)
 }
 
 }  // namespace frp

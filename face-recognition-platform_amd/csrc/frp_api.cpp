@@ -1013,7 +1013,6 @@ int frp_detect_resident(frp_handle* h, int32_t B, int32_t det_h, int32_t det_w, 
     if (B != h->rB) return fail(h, FRP_ERR_INVALID, "detect_resident: buffers sized for another resident batch");
     FRPCHK(select_det_source(h, det_h, det_w));
     FRPCHK(run_detect(h, max_faces, det_thresh, nms_iou, flags));
-    const int B = h->rB;
     const size_t s = (size_t)B * max_faces;
     if (boxes) HIPCHK(h, hipMemcpyAsync(boxes, h->boxes.p, s * 16, hipMemcpyDeviceToHost, h->stream));
     if (kps) HIPCHK(h, hipMemcpyAsync(kps, h->kps.p, s * 40, hipMemcpyDeviceToHost, h->stream));
@@ -1410,6 +1409,34 @@ int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* t
     if (rc != FRP_OK) return rc;
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("mfma_peak: ") + hipGetErrorString(e));
     *tflops = (float)((double)blocks * (lds_reads ? 8.0 * 16 : 4.0 * 4) * iters * 32768.0 / (ms * 1e-3) / 1e12);
+    return FRP_OK;
+}
+
+int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!tflops || iters <= 0) return fail(h, FRP_ERR_INVALID, "bad arguments");
+    const int blocks = h->n_cu;
+    DevBuf src, dst;
+    int rc = ensure(h, src, 4u << 20);        // LDS image + the 4 MiB window the lab's LDS-DMA variants read
+    if (rc == FRP_OK) rc = ensure(h, dst, (size_t)blocks * 512 * 4);
+    hipError_t e = hipSuccess;
+    float ms = 0.f;
+    if (rc == FRP_OK) {
+        e = launch_fill_random_f16((_Float16*)src.p, 2L << 20, 7u, 1.0f, h->stream);
+        if (e == hipSuccess) e = launch_kstep_lab((const _Float16*)src.p, (float*)dst.p, blocks, variant, iters, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev[0], h->stream);
+        if (e == hipSuccess) e = launch_kstep_lab((const _Float16*)src.p, (float*)dst.p, blocks, variant, iters, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(h->ev[1], h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    release(src);
+    release(dst);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("kstep_lab: ") + hipGetErrorString(e));
+    *tflops = (float)((double)blocks * 8.0 * 16 * kstep_lab_steps_per_iter(variant) * iters * 32768.0 / (ms * 1e-3) / 1e12);
     return FRP_OK;
 }
 

@@ -40,6 +40,7 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
 // routes eligible shapes to it.  `p` must carry launch_conv()'s derived fields.
 bool conv3x3_rows_eligible(const ConvParams& p);
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // static k-loop generation (conv3x3_lean.hip)
 
 // K1: u8 BGR frames -> normalised fp16 NHWC8 canvas (top-left letterbox, zero u8 pad)
 hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,
@@ -137,6 +138,9 @@ hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int 
 hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream);
 // the conv k-step's MFMA + ds_read_b128 mix without memory traffic or barriers (reads per 4 MFMAs: 4, 3 or 2)
 hipError_t launch_mfma_lds(const _Float16* src, float* dst, int blocks, int reads, int iters, hipStream_t stream);
+// tuning lab: schedules of the conv k-step's inner loop in isolation (kstep_lab.hip)
+hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int variant, int iters, hipStream_t stream);
+int kstep_lab_steps_per_iter(int variant);
 hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream);
 
 // K6: cosine match, top-1 (and optional full score matrix)

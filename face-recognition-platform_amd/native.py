@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
-    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_get_counters", "frp_reset_counters",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
     lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib.frp_kstep_lab.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
     lib.frp_reset_counters.argtypes = [vp]
     _lib = lib
@@ -417,6 +418,12 @@ class Engine:
         """TFLOP/s of the conv k-step's instruction mix alone (8 waves per CU, 64x64 wave tiles, fragments from LDS
         by ds_read_b128, random data, no DMA / barriers / epilogue): the ceiling of that wave layout"""
         return self.mfma_peak(16 * int(reads_per_4_mfma) + 2, iters)
+
+    def kstep_lab(self, variant: int, iters: int = 3000) -> float:
+        """TFLOP/s of the conv k-step's inner loop in isolation under schedule `variant` (csrc/kstep_lab.hip)"""
+        t = C.c_float()
+        self._chk(self._lib.frp_kstep_lab(self._h, int(variant), int(iters), C.byref(t)))
+        return float(t.value)
 
     def counters(self) -> dict:
         c = FrpCounters()

@@ -210,6 +210,9 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
  * or - waves_per_simd = 16*r + 2, r in {4,3,2} - of the conv k-step's mix: 8 waves per CU, r ds_read_b128 per 4 MFMAs */
 int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops);
 
+/* tuning hook: the conv k-step's inner loop in isolation under different schedules (csrc/kstep_lab.hip) */
+int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops);
+
 /* ---- observability ---------------------------------------------------------------
  * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */
 int frp_get_counters(frp_handle* h, frp_counters* out);
