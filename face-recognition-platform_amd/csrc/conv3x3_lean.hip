@@ -193,11 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         for (int q = 0; q < 5; ++q) x_piece(cur, q, r, 0, r);
         w_stage(cur, r, 0, r);
     }
-    const bool out32 = p.flags & FRP_FLAG_OUT_F32;
-    const bool up2 = p.flags & FRP_FLAG_RES_UP2;
     const bool has_res = p.res != nullptr;
-    const bool prelu = p.act == FRP_ACT_PRELU;
-    const bool relu = p.act == FRP_ACT_RELU;
 
     // ---------------- epilogue of a tile (as conv3x3_rows.hip): bias / border-class bias from the LDS parameter cache,
     // residual (requested one k-step early), activation in fp32, 16-byte fp16 stores after a half-wave exchange
@@ -206,114 +202,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     uint4 rres[MP][MC][2];
     int fr_e = fr, fh_e = fh;
     auto issue_residual_loads = [&](int m0, int c0) __attribute__((always_inline)) {
-        const int fr = fr_e, fh = fh_e;
-#pragma unroll
-        for (int i = 0; i < MP; ++i) {
-            const int mraw = m0 + prow0 + i * 32 + fr;
-            const int m = mraw < p.M ? mraw : 0;
-            long ridx = (long)m * p.Cout;
-            if (up2) {
-                int n, rem, oy, ox;
-                fast_divmod(m, HoWo, inv_howo, n, rem);
-                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
-            }
-#pragma unroll
-            for (int j = 0; j < MC; ++j)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
-                    rres[i][j][q] = *reinterpret_cast<const uint4*>(p.res + ridx + (co < p.Cout ? co : 0));
-                }
-        }
-    };
-    auto epilogue_body = [&](auto FULL_T, int m0, int c0) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(FULL_T)::value;
-        const int fr = fr_e, fh = fh_e;
-        half4 r4[MP][MC][4];
-        bool mok[MP];
-        long obase[MP];
-        int cls[MP];
-#pragma unroll
-        for (int i = 0; i < MP; ++i) {
-            const int mraw = m0 + prow0 + i * 32 + fr;
-            mok[i] = FULL || mraw < p.M;
-            const int m = mok[i] ? mraw : 0;
-            cls[i] = 0;
-            if (border) {
-                int n, rem, oy, ox;
-                fast_divmod(m, HoWo, inv_howo, n, rem);
-                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-            }
-            obase[i] = (long)m * p.Cout;
-            if (has_res) {
-#pragma unroll
-                for (int j = 0; j < MC; ++j)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        uint4 rr = rres[i][j][q];
-                        swap_halves(rr.x, rr.z);
-                        swap_halves(rr.y, rr.w);
-                        union { unsigned u[2]; half4 h; } lo, hi;
-                        lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
-                        r4[i][j][2 * q] = lo.h;
-                        r4[i][j][2 * q + 1] = hi.h;
-                    }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MP; ++i) {
-#pragma unroll
-            for (int j = 0; j < MC; ++j) {
-                floatx4 v[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
-                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
-                    if (has_res) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
-                    }
-                    if (relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
-                    } else if (prelu) {
-                        const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
-                    }
-                }
-                if (out32) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                        if (FULL || (mok[i] && co < p.Cout))
-                            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
-                    }
-                } else {
-                    union { half4 h; unsigned u[2]; } pk[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
-                        swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
-                        const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
-                        if (FULL || (mok[i] && co < p.Cout))
-                            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
-                                make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
-                    }
-                }
-            }
-        }
+        conv_residual_loads<MP, MC>(p, rres, m0, c0, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
     };
     auto run_epilogue = [&](int m0, int c0) __attribute__((always_inline)) {
-        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}, m0, c0); else epilogue_body(std::false_type{}, m0, c0);
+        conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
     };
 
     stamp(p.stamps, 1);

@@ -63,6 +63,152 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
     if (r >= d) { ++q; r -= d; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile epilogue shared by the conv kernels (accumulator layout of v_mfma_f32_32x32x16: lane = one pixel (fr) of a
+// 32-pixel row block, registers 4g..4g+3 = couts 8g + 4*fh .. +3 of a 32-cout block): bias / 9-class border bias
+// from the LDS parameter cache, residual, activation in fp32, then fp16 (16-byte stores after a half-wave
+// exchange) or fp32 output.
+//
+// FULL tiles (the common case) run a copy specialised at compile time on (activation, residual): with the flags
+// as run-time values the compiler kept ~70 uniform branches and ~90 s_nops in every epilogue (it does not unswitch
+// a body this large), a quarter of its instructions.  Ragged tiles and fp32 output take the generic copy.
+//   ACT: FRP_ACT_* or -1 = run-time p.act;  RES: 0 / 1 or -1 = run-time.
+template <int MP, int MC, int TC, bool FULL, int ACT, int RES>
+__device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
+                                                   const float* lds_bias, const float* lds_slope, int m0, int c0, int prow0,
+                                                   int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
+    const bool out32 = (ACT < 0) && (p.flags & FRP_FLAG_OUT_F32);
+    const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
+    const int act = ACT < 0 ? p.act : ACT;
+    half4 r4[MP][MC][4];
+    bool mok[MP];
+    long obase[MP];
+    int cls[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const int mraw = m0 + prow0 + i * 32 + fr;
+        mok[i] = FULL || mraw < p.M;
+        const int m = mok[i] ? mraw : 0;
+        cls[i] = 0;
+        if (border) {
+            int n, rem, oy, ox;
+            fast_divmod(m, HoWo, inv_howo, n, rem);
+            fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+            cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+        }
+        obase[i] = (long)m * p.Cout;
+        if (has_res) {
+            // the residual arrived as 16-byte chunks in the STORE layout; the same half-wave exchange as for the
+            // stores (it is its own inverse) turns them into the accumulator layout
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    uint4 rr = rres[i][j][q];
+                    swap_halves(rr.x, rr.z);
+                    swap_halves(rr.y, rr.w);
+                    union { unsigned u[2]; half4 h; } lo, hi;
+                    lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
+                    r4[i][j][2 * q] = lo.h;
+                    r4[i][j][2 * q + 1] = hi.h;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            floatx4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
+                }
+                if (act == FRP_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                } else if (act == FRP_ACT_PRELU) {
+                    const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
+                }
+            }
+            if (out32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
+                    if (FULL || (mok[i] && co < p.Cout))
+                        *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
+                }
+            } else {
+                union { half4 h; unsigned u[2]; } pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                    swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;   // 8 consecutive couts
+                    if (FULL || (mok[i] && co < p.Cout))
+                        *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
+                            make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
+                }
+            }
+        }
+    }
+}
+
+template <int MP, int MC, int TC>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
+                                              const float* lds_bias, const float* lds_slope, int m0, int c0, int TP, int prow0,
+                                              int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+#define FRP_EPI(FULL_, ACT_, RES_) \
+    conv_epilogue_body<MP, MC, TC, FULL_, ACT_, RES_>(p, acc, rres, lds_bias, lds_slope, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo)
+    const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
+    if (!full) { FRP_EPI(false, -1, -1); return; }
+    if (p.flags & FRP_FLAG_OUT_F32) { FRP_EPI(true, -1, -1); return; }
+    const bool has_res = p.res != nullptr;
+    if (p.act == FRP_ACT_PRELU) { if (has_res) FRP_EPI(true, FRP_ACT_PRELU, 1); else FRP_EPI(true, FRP_ACT_PRELU, 0); }
+    else if (p.act == FRP_ACT_RELU) { if (has_res) FRP_EPI(true, FRP_ACT_RELU, 1); else FRP_EPI(true, FRP_ACT_RELU, 0); }
+    else { if (has_res) FRP_EPI(true, FRP_ACT_NONE, 1); else FRP_EPI(true, FRP_ACT_NONE, 0); }
+#undef FRP_EPI
+}
+
+// residual of a tile in the STORE layout (16-byte chunks: couts 16q + 8*fh .. +7 of this lane's pixel), from clamped -
+// always valid - addresses; consumed by conv_epilogue
+template <int MP, int MC>
+__device__ __forceinline__ void conv_residual_loads(const ConvParams& p, uint4 (&rres)[MP][MC][2], int m0, int c0, int prow0, int crow0,
+                                                    int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+    const bool up2 = p.flags & FRP_FLAG_RES_UP2;
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const int mraw = m0 + prow0 + i * 32 + fr;
+        const int m = mraw < p.M ? mraw : 0;
+        long ridx = (long)m * p.Cout;
+        if (up2) {
+            int n, rem, oy, ox;
+            fast_divmod(m, HoWo, inv_howo, n, rem);
+            fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+            ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
+        }
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                rres[i][j][q] = *reinterpret_cast<const uint4*>(p.res + ridx + (co < p.Cout ? co : 0));
+            }
+    }
+}
+
 __device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int N>

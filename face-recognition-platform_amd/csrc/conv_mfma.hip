@@ -282,12 +282,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
         }
     }
     int buf = 0, consumed = 0;
-    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
-    const bool out32 = p.flags & FRP_FLAG_OUT_F32;
-    const bool up2 = p.flags & FRP_FLAG_RES_UP2;
     const bool has_res = p.res != nullptr;
-    const bool prelu = p.act == FRP_ACT_PRELU;
-    const bool relu = p.act == FRP_ACT_RELU;
 
     stamp(p.stamps, 1);
     for (int ct = t0; ct < t1; ct += tstep) {
@@ -385,98 +380,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
         // issued up front (32 VGPRs).  Interior tiles (the common case) take a copy of the body with
         // unconditional stores; ragged tiles clamp the load addresses and predicate the stores.
         if (nk == 1) __syncthreads();             // params were written in this very k-step
-        auto epilogue_body = [&](auto FULL_T) {
-            constexpr bool FULL = decltype(FULL_T)::value;
-            half4 r4[MP][MC][4];
-            bool mok[MP];
-            long obase[MP];
-            int cls[MP];
-#pragma unroll
-            for (int i = 0; i < MP; ++i) {
-                const int mraw = m0 + prow0 + i * 32 + fr;
-                mok[i] = FULL || mraw < p.M;
-                const int m = mok[i] ? mraw : 0;
-                long ridx = (long)m * p.Cout;
-                cls[i] = 0;
-                if (border || up2) {
-                    int n, rem, oy, ox;
-                    fast_divmod(m, HoWo, inv_howo, n, rem);
-                    fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                    if (border) cls[i] = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
-                    if (up2) ridx = (((long)n * p.Hr + (oy >> 1)) * p.Wr + (ox >> 1)) * p.Cout;
-                }
-                obase[i] = (long)m * p.Cout;
-                if (has_res) {
-                    // 16-byte loads in the STORE layout (couts 16q + 8*fh .. +7 of this pixel), then the same half-wave
-                    // exchange as for the stores (it is its own inverse) back into the accumulator layout: half as many,
-                    // twice as wide loads as reading the 4-cout accumulator runs directly
-#pragma unroll
-                    for (int j = 0; j < MC; ++j)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
-                            uint4 rr = *reinterpret_cast<const uint4*>(p.res + ridx + ((FULL || co < p.Cout) ? co : 0));
-                            swap_halves(rr.x, rr.z);
-                            swap_halves(rr.y, rr.w);
-                            union { unsigned u[2]; half4 h; } lo, hi;
-                            lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
-                            r4[i][j][2 * q] = lo.h;
-                            r4[i][j][2 * q + 1] = hi.h;
-                        }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MP; ++i) {
-#pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    floatx4 v[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = crow0 + j * 32 + 8 * g + 4 * fh;          // cout inside the tile
-                        const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls[i] * TC + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
-                        if (has_res) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[i][j][g][e];
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
-                        } else if (prelu) {
-                            const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
-                        }
-                    }
-                    if (out32) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int co = c0 + crow0 + j * 32 + 8 * g + 4 * fh;
-                            if (FULL || (mok[i] && co < p.Cout))
-                                *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + obase[i] + co) = v[g];
-                        }
-                    } else {
-                        // fp16: exchange between the half-waves so every lane stores 16 contiguous bytes
-                        union { half4 h; unsigned u[2]; } pk[4];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
-                            swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
-                            const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;   // 8 consecutive couts
-                            if (FULL || (mok[i] && co < p.Cout))
-                                *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase[i] + co) =
-                                    make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
-                        }
-                    }
-                }
-            }
-        };
-        if (m0 + TP <= p.M && c0 + TC <= p.Cout) epilogue_body(std::true_type{}); else epilogue_body(std::false_type{});
+        {
+            uint4 rres[MP][MC][2];
+            if (has_res) conv_residual_loads<MP, MC>(p, rres, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
+            conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
+        }
         if (ct == t0) stamp(p.stamps, 5);                      // first tile's epilogue issued
     }
     stamp(p.stamps, 6);                                        // all tiles done (after the last epilogue's issue)

@@ -367,6 +367,9 @@ def test_malformed_blobs_are_rejected_not_executed(engine):
         "stride": with_op(3, stride=3),
         "activation": with_op(3, act=7),
         "fp8 flag without room for the scales": with_op(n_det - 1, flags=ops[n_det - 1][8] | 16, w_off=data_bytes - 256),
+        "op table offset that wraps in 64 bits": with_header(f19=2 ** 64 - 64),
+        "upsampled residual without a residual": with_op(3, res_buf=-1, flags=ops[3][8] | 4),
+        "residual id below -1": with_op(res_i, res_buf=-7),
     }
     for name, bad in load_time.items():
         with pytest.raises(FrpError):
@@ -415,6 +418,9 @@ def test_c_abi_rejects_bad_arguments(engine):
     o = engine._alloc(1, 4)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)     # noqa: E731
     outs = [ptr(o["boxes"]), ptr(o["kps"]), ptr(o["scores"]), ptr(o["counts"]), ptr(o["emb"]), ptr(o["match_idx"]), ptr(o["match_cos"])]
+    G0 = np.random.default_rng(5).standard_normal((8, 512)).astype(np.float32)
+    engine.gallery_set(G0)
+    engine.process_frames(f, max_faces=4, flags=1)     # leaves results of shape (B=1, K=4) and one resident frame on the handle
     bad_calls = [
         lambda: lib.frp_process_frames(h, None, 1, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),
         lambda: lib.frp_process_frames(h, ptr(f), 0, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),
@@ -425,7 +431,15 @@ def test_c_abi_rejects_bad_arguments(engine):
         lambda: lib.frp_upload_frames(h, None, 1, 64, 64, 192),
         lambda: lib.frp_upload_frames_async(h, ptr(f), 1, -3, 64, 192),
         lambda: lib.frp_match(h, None, 1, 1, ptr(o["match_idx"]), ptr(o["match_cos"])),
-        lambda: lib.frp_match_scores(h, ptr(o["emb"]), 1, None),
+        lambda: lib.frp_match_scores(h, ptr(o["emb"]), 1, None, engine.gallery_size()),
+        # caller-sized buffers that no longer match the handle's state (a concurrent caller changed it): refused under
+        # the handle mutex, nothing written
+        lambda: lib.frp_match_scores(h, ptr(o["emb"]), 1, ptr(o["emb"]), engine.gallery_size() + 1),
+        lambda: lib.frp_fetch_results(h, 7, 4, *outs),
+        lambda: lib.frp_fetch_results(h, 1, 3, *outs),
+        lambda: lib.frp_finish_faces(h, 9, ptr(o["boxes"]), ptr(o["kps"]), ptr(o["scores"]), ptr(o["counts"]), 4, 0, ptr(o["emb"]),
+                                     ptr(o["match_idx"]), ptr(o["match_cos"])),
+        lambda: lib.frp_detect_resident(h, 9, 64, 64, 4, 0.5, 0.4, 0, ptr(o["boxes"]), ptr(o["kps"]), ptr(o["scores"]), ptr(o["counts"]), None),
         lambda: lib.frp_gallery_set(h, None, 5, 512, 0),
         lambda: lib.frp_gallery_set(h, ptr(o["emb"]), 1, 128, 0),                                 # wrong dimension
         lambda: lib.frp_gallery_remove_row(h, 10 ** 9),
@@ -433,6 +447,8 @@ def test_c_abi_rejects_bad_arguments(engine):
         lambda: lib.frp_embed_aligned(h, None, 3, ptr(o["emb"])),
         lambda: lib.frp_conv2d_nhwc(h, ptr(f), 1, 8, 8, 24, ptr(f), 32, 3, 1, ptr(o["scores"]), None, None, 0, 0, 0, 0, ptr(o["emb"])),
         lambda: lib.frp_process_frames(None, ptr(f), 1, 64, 64, 192, 4, 0.5, 0.4, 0, *outs),      # null handle
+        lambda: lib.frp_conv_bench(h, 1, 8, 8, 64, 64, 3, 0, 0, 0, 0, 1, C.byref(C.c_float()), None),   # stride 0
+        lambda: lib.frp_conv_bench(h, 1, 8, 8, 64, 64, 2, 1, 0, 0, 0, 1, C.byref(C.c_float()), None),   # kernel size 2
     ]
     for i, call in enumerate(bad_calls):
         assert call() < 0, i

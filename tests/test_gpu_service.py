@@ -112,3 +112,89 @@ def test_concurrent_callers_share_one_handle(engine):
         for k in ("boxes", "emb", "match_idx", "match_cos"):
             assert np.array_equal(a[k], b[k]), k
     engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_a14_duplicate_scan_and_cluster_on_device_vs_reference_golden(engine):
+    """SURVEY 8a row a14 on the device: store_face's duplicate scan (first hit in dict order, d < 0.3,
+    face_service.py:349-364) and greedy cluster_faces (:552-585) over device score rows - cluster_faces scores
+    CLUSTER_TILE candidate seeds per gallery pass - against the fixtures the reference's own FaceService produced."""
+    meta = json.load(open(os.path.join(HERE, "golden", "plumbing_golden.json")))
+    arrays = np.load(os.path.join(HERE, "golden", "plumbing_golden.npz"))
+    import frp_amd.face_service as fsmod
+    for tile in (64, 3):                       # 3: several tiles per sweep, seeds skipped inside a tile
+        fsmod.CLUSTER_TILE = tile
+        for case in meta["cases"]:
+            if case["D"] != 512:
+                continue
+            G = arrays[f"case{case['id']}_G"]
+            fs = FaceService(engine=engine)
+            fs.ENCODINGS.clear()
+            for n, g in zip(case["names"], G):
+                assert fs.store_face(n, g)["success"]
+            D = np.sqrt(np.maximum(0, 2 - 2 * (G @ G.T)))
+            for t, exp in case["clusters"].items():
+                # fp16 gallery rows: a pair within 2e-3 of the threshold may fall on either side
+                if np.abs(D - float(t)).min() < 2e-3:
+                    continue
+                assert fs.cluster_faces(float(t)) == exp, (case["id"], t, tile)
+            dup = arrays[f"case{case['id']}_dup"]
+            assert fs.store_face("new_person", dup / np.linalg.norm(dup)) == case["store_dup"]
+            assert fs.store_face(case["names"][0], G[0]) == case["store_update"]
+            assert fs.get_all_targets() == case["targets_after"]
+            fs.ENCODINGS.clear()
+    fsmod.CLUSTER_TILE = 64
+
+
+def test_store_and_delete_race_compare_and_process(engine):
+    """one FaceService shared by threads: enrol / delete identities while others compare and process frames.
+    Every answer must be consistent with SOME gallery state: a returned target name is the identity whose embedding
+    matches, never the one swapped into its row; no exception, no buffer overrun (capacity-checked C ABI)."""
+    import threading
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(12)
+    E = rng.standard_normal((40, 512)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    fs = FaceService(engine=engine)
+    fs.ENCODINGS.clear()
+    for i in range(20):
+        fs.store_face(f"id{i}", E[i])
+    frames = rng.integers(0, 256, size=(2, 96, 128, 3), dtype=np.uint8)
+    stop = threading.Event()
+    errs = []
+
+    def churn():
+        try:
+            k = 0
+            while not stop.is_set():
+                i = 20 + k % 20
+                assert fs.store_face(f"id{i}", E[i])["success"]            # ids 20..39 come and go, 0..19 stay
+                if k >= 5:
+                    assert fs.delete_face(f"id{20 + (k - 5) % 20}")["success"]
+                k += 1
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    def readers():
+        try:
+            for r in range(60):
+                i = r % 20
+                res = fs.compare_faces(E[i])
+                assert res and res[0]["target"] == f"id{i}" and res[0]["distance"] < 0.05, res[:1]
+                nn = fs.find_k_nearest(E[i], 3)
+                assert nn[0]["target"] == f"id{i}"
+                b = fs.batch_compare_faces([E[i], E[(i + 1) % 20]])
+                assert b[0][0]["target"] == f"id{i}" and b[1][0]["target"] == f"id{(i + 1) % 20}"
+                out = fs.process_frames(frames, max_faces=2, det_thresh=0.0)
+                assert len(out) == 2
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=churn)] + [threading.Thread(target=readers) for _ in range(3)]
+    [t.start() for t in ts[1:]]
+    ts[0].start()
+    [t.join() for t in ts[1:]]
+    stop.set()
+    ts[0].join()
+    assert not errs, errs[:2]
+    fs.ENCODINGS.clear()

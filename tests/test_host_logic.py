@@ -112,6 +112,75 @@ def test_gallery_name_table_survives_delete_and_update():
     assert fs.find_k_nearest(E[1], 1)[0]["target"] == "p2"
 
 
+def test_delete_between_match_and_lookup_cannot_misattribute():
+    """store/delete move device rows (swap-remove).  A delete that lands between the device match and the row -> name
+    lookup must not attribute the face to the identity that was moved into its row (the reference builds names and
+    matrix in one call, face_service.py:403-411): readers hold the gallery lock across both."""
+    import threading
+    rng = np.random.default_rng(3)
+    E = rng.standard_normal((6, 512))
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+
+    class SlowEngine(FakeEngine):
+        """lets a deleter run while the 'device' call is in flight"""
+        def __init__(self):
+            super().__init__()
+            self.in_call = threading.Event()
+            self.go = threading.Event()
+
+        def match(self, q, topk=1):
+            r = super().match(q, topk)
+            self.in_call.set()
+            self.go.wait(2.0)
+            return r
+
+    eng = SlowEngine()
+    fs = FaceService(engine=eng)
+    for i in range(6):
+        fs.store_face(f"p{i}", E[i])
+    out = {}
+    t = threading.Thread(target=lambda: out.setdefault("r", fs.find_k_nearest(E[1], 1)))
+    t.start()
+    assert eng.in_call.wait(2.0)
+    d = threading.Thread(target=lambda: out.setdefault("d", fs.delete_face("p1")))   # row 1 <- p5 (swap-remove)
+    d.start()
+    d.join(0.2)
+    assert d.is_alive()                      # the delete waits for the reader's lock instead of racing the lookup
+    eng.go.set()
+    t.join()
+    d.join()
+    assert out["r"][0]["target"] == "p1" and out["d"]["success"]
+    assert fs.find_k_nearest(E[5], 1)[0]["target"] == "p5"
+
+
+def test_match_scores_buffer_follows_gallery_growth():
+    """native.Engine.match_scores sizes its output from gallery_size(); the library refuses (and the binding
+    retries) when the gallery changed in between - exercised here through the same retry loop on a stub library"""
+    from frp_amd import native
+
+    class Lib:
+        def __init__(self):
+            self.n = 5
+            self.calls = 0
+
+        def frp_gallery_size(self, h):
+            return self.n
+
+        def frp_match_scores(self, h, q, m, out, n_cols):
+            self.calls += 1
+            if self.calls == 1:
+                self.n = 6                   # a store_face slipped in: capacity no longer matches
+            return 0 if n_cols == self.n else -1
+
+        def frp_last_error(self, h):
+            return b"match_scores: output sized for another gallery size"
+
+    eng = native.Engine.__new__(native.Engine)
+    eng._lib, eng._h = Lib(), None
+    out = eng.match_scores(np.zeros((2, 512), np.float32))
+    assert out.shape == (2, 6) and eng._lib.calls == 2
+
+
 def test_quality_matches_reference_geometry_and_formulas(golden):
     meta, _ = golden
     fs = FaceService(engine=FakeEngine())
