@@ -163,13 +163,89 @@ __global__ __launch_bounds__(512, 2) void kstep_lab_kernel(const _Float16* __res
     dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The same k-step on v_mfma_f32_16x16x32_f16: 64x64 wave tile = 4x4 blocks of 16x16, a 64-deep stage = two 32-deep
+// slabs of 8 fragment reads (4 A + 4 B) and 16 MFMAs each.  V: bit 0 barrier, bit 2 cross-barrier prefetch, bits 6..8 DMA.
+template <int V>
+__global__ __launch_bounds__(512, 2) void kstep_lab16_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 384 * 128];
+    for (int i = threadIdx.x; i < 3 * 384 * 128 / 16; i += 512)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, kg = lane >> 4;
+    const int prow0 = (wave >> 1) * 64, crow0 = 256 + (wave & 1) * 64;
+    constexpr bool BAR = V & 1, PF = V & 4;
+    constexpr int P = (V >> 6) & 7;
+    floatx4 acc[4][4] = {};
+    half8 f[2][8];
+    int addr[8][2];                       // [fragment][slab] byte offset inside a stage
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int row = (q < 4 ? prow0 + q * 16 : crow0 + (q - 4) * 16) + fr;
+            addr[q][sl] = row * 128 + (((4 * sl + kg) ^ ((row >> 1) & 7)) << 4);
+        }
+    auto rd = [&](int soff, int sl, int S) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[S][q] = *reinterpret_cast<const half8*>(lds + soff + addr[q][sl]);
+    };
+    auto mm = [&](int S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[S][4 + j], f[S][i], acc[i][j], 0, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4u << 20, 0x00020000);
+    unsigned goff = ((blockIdx.x * 8 + wave) * 8192u + lane * 16u) & ((4u << 20) - 1);
+    auto dma = [&](int slot, int piece) {
+        if constexpr (P > 0) {
+            dma16(rsrc, lds + slot * (384 * 128) + ((piece * 8 + wave) % 48) * 1024, goff);
+            goff = (goff + 1024u) & ((4u << 20) - 1);
+        }
+    };
+    auto dma_half = [&](int slot, int hlf) {
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if ((q & 1) == hlf) dma(slot, q);
+    };
+    if constexpr (P > 0) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) dma(1, q);
+#pragma unroll
+        for (int q = 0; q < P; ++q) dma(2, q);
+    }
+    int stage = 0;
+    if constexpr (PF) rd(0, 0, 0);
+    for (int it = 0; it < iters; ++it) {
+        const int soff = stage * (384 * 128);
+        const int nstage = stage == 2 ? 0 : stage + 1;
+        const int wslot = stage == 0 ? 2 : stage - 1;
+        if constexpr (P > 0) wait_vmcnt<P>();
+        if constexpr (BAR) { if constexpr (PF) wait_lgkmcnt0(); __builtin_amdgcn_s_barrier(); }
+        if constexpr (!PF) rd(soff, 0, 0);
+        rd(soff, 1, 1); mm(0); dma_half(wslot, 0);
+        if constexpr (PF) rd(nstage * (384 * 128), 0, 0);
+        mm(1); dma_half(wslot, 1);
+        stage = nstage;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int V>
 static void lab_launch(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream) {
     hipLaunchKernelGGL(kstep_lab_kernel<V>, dim3(blocks), dim3(512), 0, stream, src, dst, iters);
 }
 
 // k-steps executed per loop iteration of a variant (the three-set variants unroll three)
-int kstep_lab_steps_per_iter(int variant) { return (variant & 32) ? 3 : 1; }
+int kstep_lab_steps_per_iter(int variant) { return ((variant & 32) && !(variant & 512)) ? 3 : 1; }
 
 hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int variant, int iters, hipStream_t stream) {
     switch (variant) {
@@ -180,6 +256,9 @@ hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int var
         LABCASE(64 * 4 + 1) LABCASE(64 * 4 + 7) LABCASE(64 * 4 + 5) LABCASE(64 * 6 + 1) LABCASE(64 * 6 + 7) LABCASE(64 * 2 + 1) LABCASE(64 * 2 + 7)
         LABCASE(64 * 4 + 0) LABCASE(64 * 3 + 1) LABCASE(64 * 3 + 7)
 #undef LABCASE
+#define LAB16(v) case 512 + v: hipLaunchKernelGGL(kstep_lab16_kernel<v>, dim3(blocks), dim3(512), 0, stream, src, dst, iters); break;
+        LAB16(0) LAB16(1) LAB16(5) LAB16(64 * 4 + 1) LAB16(64 * 4 + 5) LAB16(64 * 4 + 0)
+#undef LAB16
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

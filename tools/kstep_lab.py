@@ -18,11 +18,13 @@ def main():
     best = {v: 0.0 for v in VARIANTS}
     for _ in range(3):
         for v in VARIANTS:
-            best[v] = max(best[v], eng.kstep_lab(v, 3000 // (3 if v & 32 else 1)))
+            best[v] = max(best[v], eng.kstep_lab(v, 3000 // (3 if (v & 32 and not v & 512) else 1)))
     for v in VARIANTS:
-        label = "+".join(n for b, n in NAMES.items() if v & b) or "free"
-        if v >> 6:
-            label += f"+dma{v >> 6}"
+        label = "+".join(n for b, n in NAMES.items() if v & b & 63) or "free"
+        if (v >> 6) & 7:
+            label += f"+dma{(v >> 6) & 7}"
+        if v & 512:
+            label += " [16x16x32]"
         print(f"variant {v:3d} {label:24s} {best[v]:8.1f} TF")
 
 

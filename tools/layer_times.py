@@ -36,7 +36,8 @@ def main():
     fused2 = "stem12_u8" in seq[0]["Kernel_Name"]
     det = walk(ns.detector_layers(), 1088, 1920, "det.in", frames)
     emb = walk(ns.iresnet_layers(), 112, 112, "emb.in", faces)
-    convs = iter(det[2 if fused2 else 1:] + emb)
+    emb_stem = any("emb_stem" in r["Kernel_Name"] for r in seq)      # the embedder's first conv runs in its own kernel
+    convs = iter(det[2 if fused2 else 1:] + emb[1 if emb_stem else 0:])
     prev_end, t0, tot, tot_gap = None, int(seq[0]["Start_Timestamp"]), 0.0, 0.0
     for r in seq:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -46,7 +47,7 @@ def main():
         tot += d
         tot_gap += gap
         name = r["Kernel_Name"]
-        if "conv_mfma" in name or "conv3x3_rows" in name:
+        if "conv_mfma" in name or "conv3x3_rows" in name or "conv3x3_lean" in name:
             l, h, w, fl = next(convs)
             cfg = re.search(r"<(\d+), (\d+),", name)
             print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
