@@ -58,6 +58,21 @@ class FrpError(RuntimeError):
 _lib = None
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the native sources (csrc/*.hip|h|cpp, include/*.h): ties a committed profile summary
+    (profiles/*/pmc_traffic.json) to the kernels it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_library() -> C.CDLL:
     """dlopen libfrp.so; raises if it has not been built (python __graft_entry__.py build)."""
     global _lib

@@ -282,6 +282,92 @@ def test_detector_head_maps_parity(engine, stem_env, shape, monkeypatch):
         assert np.all(g[..., 30:] == 0)
 
 
+def _emulate_program_fp16(raw, layers, x16, want):
+    """The detector / embedder PROGRAM as the device runs it, emulated in fp32 torch-CPU: BatchNorms folded by
+    weights.fold_layer, fp16 weights, every activation rounded to fp16 between layers.  Against this the kernels may
+    differ by fp32 summation order only, so the bound is a few fp16 ulps instead of the fp16-vs-fp32-network budget."""
+    from frp_amd import weights as wts
+    from frp_amd import netspec as ns
+    tens = {layers[0].src: x16}
+    for l in layers:
+        w16, bias, slope = wts.fold_layer(raw, l)
+        x = tens[l.src]
+        if l.flags & ns.FLAG_FLATTEN:
+            x = x.reshape(x.shape[0], 1, 1, -1)
+        res = tens[l.res] if l.res else None
+        y = _conv_ref(x, w16, bias, l.stride, l.act, slope, res, l.flags & 5)
+        tens[l.dst] = y.astype(np.float32 if (l.flags & ns.FLAG_OUT_F32) else np.float16)
+    return [tens[n] for n in want]
+
+
+@pytest.mark.parametrize("shape", [(2, 150, 200), (1, 97, 131)])
+def test_detector_program_matches_fp16_emulation(engine, shape):
+    """head maps of the HIP detector vs the same folded fp16 program emulated layer by layer (fp16 storage between
+    layers, fp32 accumulate): isolates kernel arithmetic from fp16 quantisation.  Bound: 4 fp16 ulps of the map's
+    scale (an ulp flip of one intermediate activation perturbs downstream sums by ~2^-11 of one term)."""
+    from frp_amd import netspec as ns
+    B, H, W = shape
+    Hc, Wc = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    rng = np.random.default_rng(77 + H)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    frames = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    engine.detect(frames, max_faces=4, det_thresh=0.5)
+    heads = engine.head_maps()
+    canvas = np.zeros((B, Hc, Wc, 3), np.uint8)
+    canvas[:, :H, :W] = frames
+    x = np.zeros((B, Hc, Wc, 8), np.float16)
+    x[..., :3] = ((canvas[..., ::-1].astype(np.float32) - 127.5) / 128.0).astype(np.float16)     # exact in fp16
+    emu = _emulate_program_fp16(raw, ns.detector_layers((1, 2, 2, 2)), x, ["det.out3", "det.out4", "det.out5"])
+    for g, r in zip(heads, emu):
+        g32, r32 = g.astype(np.float32), r.astype(np.float32)
+        scale = max(1.0, float(np.abs(r32).max()))
+        assert np.abs(g32 - r32).max() <= 4 * 2.0 ** -10 * scale, float(np.abs(g32 - r32).max() / scale)
+        assert np.mean(g.view(np.uint16) == r.view(np.uint16)) > 0.9
+
+
+def test_decode_threshold_one_ulp_and_exact_iou_tie(engine):
+    """(1) the score threshold placed BETWEEN two adjacent fp16 logit values: the upper one is a candidate, the lower
+    one is not - on the device exactly as in the oracle (no fp16/fp32 conversion slack);  (2) two boxes whose IoU
+    is exactly the NMS threshold (80 / 200 with +1 areas, nms_iou 0.4): 'suppress if IoU > threshold' keeps both."""
+    def head_set():
+        return [np.zeros((1, 64 // s, 64 // s, 32), np.float16) for s in (8, 16, 32)]
+    # (1) two far-apart anchors with logits L and prev(L)
+    L = np.float16(1.25)
+    Lm = np.nextafter(L, np.float16(-10), dtype=np.float16)
+    h = head_set()
+    for hm in h:
+        hm[..., 0] = -9.0
+        hm[..., 15] = -9.0
+        hm[..., 1:5] = 0.1
+        hm[..., 16:20] = 0.1
+    h[0][0, 1, 1, 0] = L
+    h[0][0, 5, 5, 0] = Lm
+    mid = (float(L) + float(Lm)) / 2
+    thr = 1.0 / (1.0 + np.exp(-mid))
+    o = engine.decode_heads(h, (64, 64), max_faces=4, det_thresh=thr, nms_iou=0.4)
+    ob, _, _, oa = onet.decode_nms([x[0] for x in h], np.float32(thr), 0.4, 4)
+    assert list(oa) == [2 * (1 * 8 + 1)] and o["counts"][0] == 1 and o["anchor_idx"][0, 0] == oa[0]
+    # threshold exactly AT the lower value: '>=' admits it
+    thr2 = float(np.float32(1.0 / (1.0 + np.exp(-float(Lm)))))
+    o2 = engine.decode_heads(h, (64, 64), max_faces=4, det_thresh=thr2, nms_iou=0.4)
+    ob2, _, _, oa2 = onet.decode_nms([x[0] for x in h], np.float32(thr2), 0.4, 4)
+    assert o2["counts"][0] == len(oa2) and np.array_equal(o2["anchor_idx"][0, :len(oa2)], oa2)
+    # (2) boxes [0,0,9,13] and [0,6,9,19]: inter 10 x 8 = 80, union 140 + 140 - 80 = 200 -> IoU = 0.4f exactly
+    h = head_set()
+    for hm in h:
+        hm[..., 0] = -9.0
+        hm[..., 15] = -9.0
+    h[0][0, 1, 1, 0:5] = [3.0, 1.0, 1.0, 0.125, 0.625]        # centre (8, 8): l, t, r, b in strides
+    h[0][0, 2, 1, 0:5] = [2.0, 1.0, 1.25, 0.125, 0.375]       # centre (8, 16)
+    for iou, want in ((0.4, 2), (0.399, 1)):
+        o = engine.decode_heads(h, (64, 64), max_faces=4, det_thresh=0.5, nms_iou=iou)
+        ob, _, _, oa = onet.decode_nms([x[0] for x in h], 0.5, iou, 4)
+        assert len(oa) == want and o["counts"][0] == want
+        assert np.array_equal(o["anchor_idx"][0, :want], oa) and np.array_equal(o["boxes"][0, :want], ob)
+    assert np.array_equal(ob[0], np.array([0, 0, 9, 13], np.float32))
+
+
 def test_fused_stems_agree_with_the_two_kernel_path(engine, monkeypatch):
     """stem12_u8_kernel vs stem_u8_kernel + generic conv: same fp16 stem1 values, fp32 accumulation in a
     different order -> head maps equal up to fp16 rounding noise; BGR and RGB inputs give the same result"""

@@ -198,3 +198,43 @@ def test_store_and_delete_race_compare_and_process(engine):
     ts[0].join()
     assert not errs, errs[:2]
     fs.ENCODINGS.clear()
+
+
+def test_locations_are_proper_boxes_with_planted_head_weights(engine, monkeypatch):
+    """face_recognition-style (top, right, bottom, left) boxes from a detector whose distance channels are planted
+    (zero weights, bias 1.5 strides): every box is a proper rectangle - top < bottom, left < right - clipped to
+    the image, in the reference's css order (face_service.py:156-163), and matches the oracle on the same weights."""
+    import frp_amd.face_service as fsmod
+    from frp_amd import weights
+    from oracle import network as onet
+    raw = dict(weights.make_synthetic_raw(7, (1, 2, 2, 2), (1, 1, 1, 1)))
+    for lv in (3, 4, 5):
+        w = raw[f"det.head{lv}.out.weight"].copy()
+        b = raw[f"det.head{lv}.out.bias"].copy()
+        for a in range(2):
+            w[a * 15 + 1: a * 15 + 5] = 0.0
+            b[a * 15 + 1: a * 15 + 5] = 1.5
+        raw[f"det.head{lv}.out.weight"], raw[f"det.head{lv}.out.bias"] = w, b
+    engine.load_weights(weights.pack_blob(raw, (1, 2, 2, 2), (1, 1, 1, 1)))
+    fs = FaceService(engine=engine)
+    monkeypatch.setattr(fsmod, "face_service", fs)
+    monkeypatch.setattr(fsmod, "DET_THRESH", 0.3)
+    rng = np.random.default_rng(9)
+    img = np.clip(rng.normal(120, 40, (160, 224, 3)), 0, 255).astype(np.uint8)       # RGB, as load_image_file returns
+    r = fs.encode_face(img, return_locations=True)
+    assert r["success"] and r["face_count"] >= 1
+    for (t, rr, b, l) in r["locations"]:
+        assert 0 <= t < b <= 160 and 0 <= l < rr <= 224, (t, rr, b, l)
+    # the oracle's decode of the device's own head maps (no fp16-vs-fp32 candidate flips): same boxes, css order
+    engine.detect(np.ascontiguousarray(img[None, ..., ::-1]), max_faces=10, det_thresh=0.3)
+    boxes, _, _, _ = onet.decode_nms([h[0] for h in engine.head_maps()], 0.3, 0.4, 10)
+    assert len(boxes) == r["face_count"]
+    for (t, rr, b, l), box in zip(r["locations"], boxes):
+        x1, y1, x2, y2 = box
+        assert abs(l - max(0, x1)) <= 1 and abs(t - max(0, y1)) <= 1 and abs(rr - min(224, x2)) <= 1 and abs(b - min(160, y2)) <= 1
+    # ... and the fp32 oracle NETWORK on the same planted weights agrees on every box it shares (0.5 px)
+    ref = onet.process_frames(raw, np.ascontiguousarray(img[None, ..., ::-1]), None, (160, 224), score_thresh=0.3, nms_iou=0.4, max_faces=10)[0]
+    if len(ref["boxes"]) == len(boxes):
+        assert np.abs(ref["boxes"] - boxes).max() <= 0.5
+    raw2, blob2 = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob2)

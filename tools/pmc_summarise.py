@@ -9,9 +9,14 @@ bytes are known).  The start-up kernels (gallery normalise, random fill) are dro
 """
 import csv
 import json
+import os
 import sys
 
-FAMILIES = ["conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel", "stem_u8_kernel", "gather_logits_kernel", "topk_rows_kernel", "preprocess_kernel", "decode_nms_kernel", "align_kernel",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frp_amd_loader  # noqa: E402,F401
+from frp_amd import native  # noqa: E402
+
+FAMILIES = ["conv3x3_lean_kernel", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel", "stem_u8_kernel", "gather_logits_kernel", "topk_rows_kernel", "preprocess_kernel", "decode_nms_kernel", "align_kernel",
             "match_kernel", "l2norm", "compact_faces", "chips_to_blob"]
 SKIP = ["normalize_rows_kernel", "fill_random", "mfma_peak"]
 
@@ -62,7 +67,7 @@ def main():
         n = max(n, n2)
         kernels[fam] = {"launches": n, "fetch_KB_raw_sum": round(fkb), "write_KB_sum": round(wkb),
                         "hbm_bytes_per_launch_corrected": round((2 * fkb + wkb) * 1024 / max(n, 1))}
-    conv = {k: sum(kernels.get(f, {}).get(k, 0) for f in ("conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel"))
+    conv = {k: sum(kernels.get(f, {}).get(k, 0) for f in ("conv3x3_lean_kernel", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel"))
             for k in ("fetch_KB_raw_sum", "write_KB_sum")}
     doc = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `bench.py --steps 2 "
@@ -70,6 +75,7 @@ def main():
                 "FETCH_SIZE counts half of a 16-B/lane streaming read -> x2; validated on match_kernel whose "
                 "algorithmic bytes are known (102.4 MB gallery + 0.33 MB queries).",
         "passes": passes,
+        "kernel_source_sha256_16": native.kernel_source_hash(),   # bench.py blanks roofline.traffic when the sources differ
         "kernels": kernels,
         "conv_traffic_bytes_per_step": round((2 * conv["fetch_KB_raw_sum"] + conv["write_KB_sum"]) * 1024 / passes),
     }
