@@ -199,6 +199,7 @@ def main():
         args.pcie_steps = args.steps
     if args.threshold_steps < 0:
         args.threshold_steps = args.steps
+    eng.set_profile(False)      # the side loops below run as a caller would: no per-stage events, no forced sync per call
     pcie = None
     if args.pcie_steps > 0 and rank == 0:
         stage = [eng.host_frames(B, H, W) for _ in range(2)]

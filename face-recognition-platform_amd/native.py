@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
-    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library() -> C.CDLL:
     lib.frp_kstep_lab.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
     lib.frp_reset_counters.argtypes = [vp]
+    lib.frp_set_profile.argtypes = [vp, i32]
     _lib = lib
     return lib
 
@@ -444,6 +445,10 @@ class Engine:
         c = FrpCounters()
         self._chk(self._lib.frp_get_counters(self._h, C.byref(c)))
         return c.as_dict()
+
+    def set_profile(self, on: bool):
+        """per-stage HIP-event timing on / off (on: every process call ends in a stream synchronise)"""
+        self._chk(self._lib.frp_set_profile(self._h, int(bool(on))))
 
     def reset_counters(self):
         self._chk(self._lib.frp_reset_counters(self._h))

@@ -217,6 +217,9 @@ int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops);
  * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */
 int frp_get_counters(frp_handle* h, frp_counters* out);
 int frp_reset_counters(frp_handle* h);
+/* switch the per-stage HIP-event timing (frp_config.profile) on or off: with it on, every process call ends in a stream
+ * synchronise so that the events can be read */
+int frp_set_profile(frp_handle* h, int32_t on);
 
 #ifdef __cplusplus
 }

@@ -323,7 +323,7 @@ def test_detector_program_matches_fp16_emulation(engine, shape):
         g32, r32 = g.astype(np.float32), r.astype(np.float32)
         scale = max(1.0, float(np.abs(r32).max()))
         assert np.abs(g32 - r32).max() <= 4 * 2.0 ** -10 * scale, float(np.abs(g32 - r32).max() / scale)
-        assert np.mean(g.view(np.uint16) == r.view(np.uint16)) > 0.9
+        assert np.abs(g32 - r32).mean() <= 2.0 ** -12 * scale         # typical deviation: well below one ulp of the scale
 
 
 def test_decode_threshold_one_ulp_and_exact_iou_tie(engine):

