@@ -593,6 +593,25 @@ void accumulate_events(frp_handle* h, bool with_h2d) {
     c.ms_total += el(with_h2d ? EV_START : EV_H2D, EV_MATCH);
 }
 
+// the split entry points (pyramid: frp_detect_resident, frp_finish_faces) account their half of the stage times
+void accumulate_detect_events(frp_handle* h) {
+    if (!h->cfg.profile) return;
+    auto el = [&](int a, int b) { float ms = 0.f; return hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) == hipSuccess ? (double)ms : 0.0; };
+    h->ctr.ms_preprocess += el(EV_H2D, EV_PRE);          // incl. the pyramid resize
+    h->ctr.ms_det_conv += el(EV_PRE, EV_DET);
+    h->ctr.ms_decode += el(EV_DET, EV_DEC);
+    h->ctr.ms_total += el(EV_H2D, EV_DEC);
+}
+void accumulate_face_events(frp_handle* h) {
+    if (!h->cfg.profile) return;
+    auto el = [&](int a, int b) { float ms = 0.f; return hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) == hipSuccess ? (double)ms : 0.0; };
+    h->ctr.ms_align += el(EV_DEC, EV_ALIGN);
+    h->ctr.ms_emb_conv += el(EV_ALIGN, EV_EMB);
+    h->ctr.ms_l2norm += el(EV_EMB, EV_L2);
+    h->ctr.ms_match += el(EV_L2, EV_MATCH);
+    h->ctr.ms_total += el(EV_DEC, EV_MATCH);
+}
+
 // page-locked staging for the result fetch, grown on demand.  Device -> PAGEABLE host copies go through the runtime's own
 // bounce buffers with whole-device synchronisation semantics: next to torch / RCCL in the process they serialised the
 // copy stream's upload of the next batch behind the fetch (the overlapped loop lost its overlap: 20 vs 14.7 ms per
@@ -1053,6 +1072,7 @@ int frp_detect_resident(frp_handle* h, int32_t B, int32_t det_h, int32_t det_w, 
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     if (B != h->rB) return fail(h, FRP_ERR_INVALID, "detect_resident: buffers sized for another resident batch");
+    rec(h, EV_H2D);
     FRPCHK(select_det_source(h, det_h, det_w));
     FRPCHK(run_detect(h, max_faces, det_thresh, nms_iou, flags));
     const size_t s = (size_t)B * max_faces;
@@ -1062,6 +1082,7 @@ int frp_detect_resident(frp_handle* h, int32_t B, int32_t det_h, int32_t det_w, 
     if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     if (anchor_idx) HIPCHK(h, hipMemcpyAsync(anchor_idx, h->anchor.p, s * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    accumulate_detect_events(h);
     h->last_nfaces = 0;
     return FRP_OK;
 }
@@ -1106,7 +1127,10 @@ int frp_finish_faces(frp_handle* h, int32_t B_in, const float* boxes, const floa
     h->last_K = K;
     rec(h, EV_DEC);
     FRPCHK(run_faces(h, K, n, flags));
-    return fetch_results(h, nullptr, nullptr, nullptr, nullptr, emb, match_idx, match_cos);
+    FRPCHK(fetch_results(h, nullptr, nullptr, nullptr, nullptr, emb, match_idx, match_cos));
+    accumulate_face_events(h);
+    h->ctr.calls += 1;
+    return FRP_OK;
 }
 
 int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl) {

@@ -273,6 +273,59 @@ def test_resize_and_pyramid_merge(engine):
     engine.gallery_set(np.zeros((0, 512), np.float32))
 
 
+def test_config4_full_size_4k_pyramid_million_gallery(engine):
+    """BASELINE config 4 at full size, end to end through one call: 1 x 3840x2160 frame, pyramid scales {1, .5, .25},
+    1M-identity gallery.  Per scale the device's detections equal the oracle's decode of the GPU's own head maps;
+    the cross-scale merge + NMS equals the oracle's independent restatement; embeddings come from the full-resolution
+    frame; top-1 over the 1M gallery is the planted identity with the cosine within 1e-3 of float64."""
+    from frp_amd import pyramid
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(404)
+    H, W = 2160, 3840
+    frame = _frames(rng, 1, 540, 960)                                   # structure at 1/4 scale ...
+    frame = np.repeat(np.repeat(frame, 4, axis=1), 4, axis=2)           # ... blown up, plus pixel noise
+    frame = np.clip(frame.astype(np.int16) + rng.integers(-6, 7, size=frame.shape), 0, 255).astype(np.uint8)
+    scales, K, thr = (1.0, 0.5, 0.25), 8, 0.30
+    engine.upload_frames(frame)
+    per, head_sets = [], []
+    for sc in scales:
+        hw = pyramid.scaled_size(H, W, sc)
+        d = engine.detect_resident(hw, max_faces=64, det_thresh=thr, nms_iou=0.4)
+        heads = engine.head_maps()
+        assert heads[0].shape[1:3] == ((hw[0] + 31) // 32 * 4, (hw[1] + 31) // 32 * 4)
+        ob, ok, osc, oa = onet.decode_nms([h[0] for h in heads], thr, 0.4, 64)
+        n = len(oa)
+        assert d["counts"][0] == n and np.array_equal(d["anchor_idx"][0, :n], oa) and np.array_equal(d["boxes"][0, :n], ob)
+        head_sets.append(heads)
+        per.append((hw, d))
+    boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), K, 0.4)
+    ob, ok, osc = onet.detect_pyramid(raw, frame[0], scales, thr, 0.4, K, 64,
+                                      head_maps_per_scale=[[h[0] for h in hs] for hs in head_sets])
+    n = len(ob)
+    assert counts[0] == n and n >= 1
+    assert np.array_equal(boxes[0, :n], ob) and np.array_equal(kps[0, :n], ok)
+    # 1M gallery with the frame's own identities planted
+    N = 1_000_000
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    e = engine.embed_faces(frame[0], kps[0, :n])
+    rows = rng.choice(N, size=n, replace=False)
+    G[rows] = e
+    engine.gallery_set(G)
+    out = engine.process_frames_pyramid(frame, scales, max_faces=K, det_thresh=thr, nms_iou=0.4)
+    assert out["counts"][0] == n and np.array_equal(out["boxes"][0, :n], ob)
+    assert np.abs(out["emb"][0, :n] - e).max() < 1e-6
+    assert np.array_equal(out["match_idx"][0, :n], rows)
+    want = (e.astype(np.float64) * G[rows].astype(np.float64)).sum(1)
+    assert np.abs(out["match_cos"][0, :n] - want).max() < 1e-3
+    # aligned chips of the full-resolution frame against the oracle's warp
+    chips = engine.align(frame[0], kps[0, :n])
+    ref = onet.emb_blob(onet.align_faces(frame[0], kps[0, :n]))
+    assert np.abs(chips[..., :3].astype(np.float32) - ref.permute(0, 2, 3, 1).numpy()).max() < 6e-3
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
 def test_resize_bit_exact(engine):
     """device bilinear resize == the oracle's rule, bit for bit (down- and up-scaling, odd sizes)"""
     raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
