@@ -171,8 +171,11 @@ def run_config4(args, json_fd):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
-                    help="config2 (default, the headline): 32 x 1080p, 100k gallery; config4: 4K pyramid, 1M gallery")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"],
+                    help="config2 (default, the headline): 32 x 1080p, 100k gallery; config4: 4K pyramid, 1M gallery; "
+                         "config5: 2 x 720p streams mixed into one batch per GPU, fp8 embedder (fp8 MFMA)")
+    ap.add_argument("--weights", default="fp16", choices=["fp16", "fp8-mfma"],
+                    help="fp8-mfma: the embedder's stage 2-4 3x3 convs run on E4M3 activations and weights (BASELINE config 5)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -197,6 +200,8 @@ def main():
     if args.workload == "config4":
         run_config4(args, json_fd)
         return
+    if args.workload == "config5":               # 16 streams over 8 GPUs = 2 per GPU, their frames mixed into one batch
+        args.height, args.width, args.weights = 720, 1280, "fp8-mfma"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,7 +222,7 @@ def main():
 
     B, K, N, H, W = args.batch, args.faces, args.gallery, args.height, args.width
     raw = weights.make_synthetic_raw(7)
-    blob = weights.pack_blob(raw)
+    blob = weights.pack_blob(raw, weight_format=args.weights)
     eng = native.Engine(local_rank, max_batch=B, max_faces=K, max_h=H, max_w=W, profile=True)
     eng.load_weights(blob)
 
@@ -230,7 +235,12 @@ def main():
         eng.gallery_set(gallery_rows(N, 0, N))
     assert eng.gallery_size() == N
 
-    frames = synth_frames(B, H, W, K, 1234 + rank)
+    if args.workload == "config5":     # two camera streams per GPU, interleaved frame by frame into the batch
+        two = [synth_frames(B // 2, H, W, K, 1234 + 2 * rank + s_) for s_ in range(2)]
+        frames = np.empty((B, H, W, 3), np.uint8)
+        frames[0::2], frames[1::2] = two[0], two[1]
+    else:
+        frames = synth_frames(B, H, W, K, 1234 + rank)
     eng.upload_frames(frames)          # inputs resident in HBM before the timed region
     flags = native.FLAG_FORCED_K
     for _ in range(args.warmup):
@@ -330,16 +340,22 @@ def main():
         conv_flops = ctr["det_conv_flops"] + ctr["emb_conv_flops"]
         launches = ctr["det_conv_launches"] + ctr["emb_conv_launches"]
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        f8 = args.weights == "fp8-mfma"
         out = {
-            "metric": "faces/sec (detect+embed+match) on 1080p @ 100k gallery",
+            "metric": ("faces/sec (detect+embed+match) on 720p mixed streams @ 100k gallery, fp8 embedder (BASELINE config 5, per GPU)"
+                       if args.workload == "config5" else "faces/sec (detect+embed+match) on 1080p @ 100k gallery"),
             "value": round(faces_total / dt, 2),
             "unit": "faces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{B}x{H}x{W} BGR frames per GPU per step resident in HBM, host results out every step, forced K={K} faces/frame, "
-                                   f"{N}-identity fp16 gallery, FRPDet detector + ArcFace IResNet-100 fp16 (synthetic seeded weights)",
+            "dtype": "f8" if f8 else "f16", "data": "synthetic",
+            "config": {"workload": f"{B}x{H}x{W} BGR frames per GPU per step resident in HBM"
+                                   + (" (2 camera streams interleaved)" if args.workload == "config5" else "") +
+                                   f", host results out every step, forced K={K} faces/frame, "
+                                   f"{N}-identity fp16 gallery, FRPDet detector fp16 + ArcFace IResNet-100 "
+                                   + ("with E4M3 activations and weights on the fp8 MFMA for the 3x3 stride-1 convs of stages 2-4 "
+                                      "(residual stream, stage 1, strided convs, FC: fp16)" if f8 else "fp16") + " (synthetic seeded weights)",
                        "frames_per_s": round(world * args.steps * B / dt, 2),
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
                        "host_to_host": pcie,
@@ -360,6 +376,14 @@ def main():
                          "algorithmic_gflop_per_step": round(conv_flops / args.steps / 1e9, 1),
                          "match_hbm_GBs": round(ctr["match_bytes"] / (ctr["ms_match"] * 1e-3) / 1e9, 1) if ctr["ms_match"] > 0 else None},
         }
+        if f8:      # the embedder family against the fp8 matrix peak (its fp16 launches included: a lower bound)
+            MFMA_PEAK_FP8 = 5000.0
+            emb_tf = ctr["emb_conv_flops"] / (ctr["ms_emb_conv"] * 1e-3) / 1e12 if ctr["ms_emb_conv"] > 0 else 0.0
+            out["roofline_fp8_embedder"] = {
+                "bound": "mfma", "kernel": "embedder conv family (conv3x3_lean_kernel<F8> on E4M3 operands + its fp16 launches)",
+                "achieved": round(emb_tf, 2), "peak": MFMA_PEAK_FP8, "unit": "TFLOP/s", "frac": round(emb_tf / MFMA_PEAK_FP8, 4),
+                "fp8_share_of_embedder_flops": round(ctr["f8_conv_flops"] / max(1.0, ctr["emb_conv_flops"]), 4),
+                "fp8_launches_per_step": ctr["f8_conv_launches"] // max(1, args.steps)}
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(raw, frames, K, N, args.cpu_frames)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

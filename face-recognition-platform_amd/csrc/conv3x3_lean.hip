@@ -29,7 +29,14 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int TC, int WP, int WC>
+// F8 (BASELINE config 5, "fp8 ArcFace weights (CDNA4 fp8 MFMA)"): activations and weights are OCP FP8 E4M3 bytes, the
+// matrix instruction is the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales.  A 128-byte LDS row is
+// then 128 channels, a k-step one tap x 128 channels = 2 MFMAs of K = 64 per 32x32 block: the same DMA pieces, LDS reads
+// and matrix cycles per step as the fp16 kernel for twice the FLOPs - and the chip holds a higher clock on fp8 operands
+// (tools/kstep_lab.py: 3.16 vs 1.27 PFLOP/s for the k-step with barrier and DMA).  Per-cout weight scales (and the input
+// tensor's scale) multiply the fp32 accumulator in the epilogue; outputs leave as fp16, as fp8, or as both.
+typedef int intx8 __attribute__((ext_vector_type(8)));
+template <int TC, int WP, int WC, bool F8>
 __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int TP = 256, NW = 8;
@@ -62,8 +69,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         tstep = 1;
     }
     if (t0 >= t1) return;
-    const int cpt = p.Cin >> 6;                // 64-channel blocks
-    const int cin2 = p.Cin * 2;                // bytes per pixel = bytes per tap in a weight row
+    constexpr int ES = F8 ? 1 : 2;             // bytes per element
+    const int cpt = (p.Cin * ES) >> 7;         // channel blocks of one 128-byte LDS row (64 fp16 / 128 fp8 channels)
+    const int cin2 = p.Cin * ES;               // bytes per pixel = bytes per tap in a weight row
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int co = c0i + (i * NW + wave) * 8 + lrow;
-            d.woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot + lchunk * 8) * 2u : CONV_OOB;
+            d.woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot * ES + lchunk * 16) : CONV_OOB;
         }
     };
     // piece q (0..3: row group wave + 8q, 4: group 32) of patch (cb byte offset cbs, kernel row kh) into ring slot `slot`
@@ -126,40 +134,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
             const int row = prow0 + i * 32 + fr + kw;
-            const int bx = (fh ^ ((row >> 1) & 7)) << 4;
+            const int bx = (((F8 ? 2 : 1) * fh) ^ ((row >> 1) & 7)) << 4;
             pv[kw][i] = row * 128 + bx;
             zv[kw][i] = OFF_Z + ((row * 128) & 128) + bx;
         }
-    int aoff[MC][4];                            // A fragment offsets inside a weight stage (+ OFF_W)
+    // fp16: kk = 0..3, a fragment is chunk 2kk + fh (16 B).  fp8: kk = 0..1, a fragment is chunks 4kk + 2fh and + 1 (32 B:
+    // the hardware pairs register slot s of A with slot s of B, so any lane -> k assignment works as long as both operands
+    // use the same one).  The kk = 0 chunk is (F8 ? 2 : 1) * fh; further kk flip address bits 5..6 (fp16) / bit 6 (fp8).
+    constexpr int NKK = F8 ? 2 : 4;
+    constexpr int KKSH = F8 ? 6 : 5;
+    int aoff[MC][NKK];                          // A fragment offsets inside a weight stage (+ OFF_W)
 #pragma unroll
     for (int j = 0; j < MC; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) aoff[j][kk] = OFF_W + lds_off(crow0 + j * 32 + fr, 2 * kk + fh);
+        for (int kk = 0; kk < NKK; ++kk) aoff[j][kk] = OFF_W + lds_off(crow0 + j * 32 + fr, F8 ? 4 * kk + 2 * fh : 2 * kk + fh);
 
     floatx16 acc[MP][MC];
-    half8 bf[2][MP], af[2][MC];
+    using frag_t = typename std::conditional<F8, intx8, half8>::type;
+    constexpr int NFS = F8 ? 1 : 2;             // fragment sets (fp8 fragments are 8 registers each: one set, the SIMD's
+    frag_t bf[NFS][MP], af[NFS][MC];            // partner wave covers the read latency)
     int bbase[MP];                              // per k-step: kk = 0 address of this lane's B rows (patch or zero block)
+    auto lds_frag = [&](int addr) -> frag_t {
+        if constexpr (F8) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(smem + addr);
+            const uint4 hi = *reinterpret_cast<const uint4*>(smem + (addr ^ 16));
+            return intx8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        } else {
+            return *reinterpret_cast<const half8*>(smem + addr);
+        }
+    };
     auto read_frags = [&](int wslot, int kw, int kk, int S) {
 #pragma unroll
-        for (int i = 0; i < MP; ++i)
-            bf[S][i] = *reinterpret_cast<const half8*>(smem + (bbase[i] ^ (kk << 5)));
+        for (int i = 0; i < MP; ++i) bf[S][i] = lds_frag(bbase[i] ^ (kk << KKSH));
 #pragma unroll
-        for (int j = 0; j < MC; ++j)
-            af[S][j] = *reinterpret_cast<const half8*>(smem + wslot * WSLOT + aoff[j][kk]);
+        for (int j = 0; j < MC; ++j) af[S][j] = lds_frag(aoff[j][kk] + wslot * WSLOT);
     };
     auto mfma_group = [&](int S) {
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
-            for (int j = 0; j < MC; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[S][j], bf[S][i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < MC; ++j) {
+                if constexpr (F8) {
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[S][j], bf[S][i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                } else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[S][j], bf[S][i], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // an empty volatile asm that "modifies" the accumulators: volatile asms keep their order, so the MFMAs before it stay
+    // in their k-step
+    auto pin_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int j = 0; j < MC; ++j) asm volatile("" : "+v"(acc[i][j]));
     };
 
     // ---------------- per-tile epilogue parameters in LDS (see conv_mfma.hip)
     float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
     float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
+    float* lds_wscale = lds_slope + TC;                                     // [TC] (fp8: weight scale x input scale)
     constexpr int PPT = (9 * TC + NW * 64 - 1) / (NW * 64);
-    float pb[PPT], ps = 0.f;
+    float pb[PPT], ps = 0.f, pw = 0.f;
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
     auto fetch_params = [&](int tile) {
         const int c0p = (tile % p.n_ctiles) * TC;
@@ -171,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
             pb[q] = (idx < nb && co < p.Cout) ? p.bias[(long)cls * p.Cout + co] : 0.f;
         }
         if (p.act == FRP_ACT_PRELU && t < TC) ps = (c0p + t < p.Cout) ? p.slope[c0p + t] : 0.f;
+        if (F8 && t < TC) pw = (c0p + t < p.Cout) ? p.wscale[c0p + t] * p.in_scale : 0.f;
     };
     auto store_params = [&]() {
 #pragma unroll
@@ -179,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
             if (idx < 9 * TC) lds_bias[idx] = pb[q];
         }
         if (t < TC) lds_slope[t] = ps;
+        if (F8 && t < TC) lds_wscale[t] = pw;
     };
 
     // ---------------- prologue: zero block; row patches (0,0), (0,1) and weight stages tap 0, 1 of the first tile
@@ -205,7 +243,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         conv_residual_loads<MP, MC>(p, rres, m0, c0, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
     };
     auto run_epilogue = [&](int m0, int c0) __attribute__((always_inline)) {
-        conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
+        if constexpr (F8)
+            conv_epilogue8<MP, MC, TC, true>(p, acc, rres, lds_bias, lds_slope, lds_wscale, m0, c0, TP, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
+        else if (p.out2)
+            conv_epilogue8<MP, MC, TC, false>(p, acc, rres, lds_bias, lds_slope, lds_wscale, m0, c0, TP, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
+        else
+            conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo);
     };
 
     stamp(p.stamps, 1);
@@ -254,20 +297,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                          \
             bbase[i] = ((tapmask[i] >> TAP) & 1u) ? (KH) * XSLOT + pv[KW][i] : zv[KW][i];                       \
         if (TAP == 0 && cb == 0) fetch_params(ct);                                                              \
+        /* fp8: left alone, the optimiser sinks all 72 MFMAs of the unrolled body below its last barrier (they touch   \
+           registers only) and the fragments of nine steps are spilled: pin_acc() ties each group to its step */  \
         read_frags(TAP % 3, KW, 0, 0);                                                                          \
-        read_frags(TAP % 3, KW, 1, 1); mfma_group(0);                                                           \
+        if constexpr (F8) { mfma_group(0); pin_acc(); }                                                         \
+        read_frags(TAP % 3, KW, 1, F8 ? 0 : 1);                                                                 \
+        if constexpr (!F8) mfma_group(0);                                                                       \
         if (TAP < 7) w_stage(cur, TAP + 2, cbs, (TAP + 2) % 3); else w_stage(nx, TAP - 7, ncbs, (TAP + 2) % 3); \
-        read_frags(TAP % 3, KW, 2, 0); mfma_group(1);                                                           \
+        if constexpr (!F8) { read_frags(TAP % 3, KW, 2, 0); mfma_group(1); }                                    \
         if ((KH) == 0) x_piece(cur, (KW) * 2 < 4 ? (KW) * 2 : 4, 2, cbs, 2);                                    \
         else x_piece(nx, (KW) * 2 < 4 ? (KW) * 2 : 4, (KH) - 1, ncbs, ((KH) + 2) % 3);                          \
-        read_frags(TAP % 3, KW, 3, 1); mfma_group(0);                                                           \
+        if constexpr (!F8) { read_frags(TAP % 3, KW, 3, 1); mfma_group(0); }                                    \
         if ((KW) < 2) {                                                                                         \
             if ((KH) == 0) x_piece(cur, (KW) * 2 + 1, 2, cbs, 2);                                               \
             else x_piece(nx, (KW) * 2 + 1, (KH) - 1, ncbs, ((KH) + 2) % 3);                                     \
         }                                                                                                       \
         /* the residual of the tile is requested under the last MFMA group (fragment set 0 is dead by then) */   \
         if (TAP == 8 && cb == cpt - 1 && has_res) issue_residual_loads(m0, c0);                                 \
-        mfma_group(1);                                                                                          \
+        mfma_group(F8 ? 0 : 1);                                                                                 \
+        if constexpr (F8) pin_acc();                                                                            \
         if (TAP == 0 && cb == 0) store_params();                                                                \
     } while (0)
 
@@ -308,14 +356,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     stamp(p.stamps, 6);
 }
 
-template <int TC, int WP, int WC>
+template <int TC, int WP, int WC, bool F8>
 static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + 255) / 256;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 10 * TC * 4;
+    const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
     static bool attr_set[64] = {};
-    auto kern = conv3x3_lean_kernel<TC, WP, WC>;
+    auto kern = conv3x3_lean_kernel<TC, WP, WC, F8>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -334,8 +382,12 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
 
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
-    if (p.Cout > 64) return launch_lean_cfg<128, 4, 2>(p, stream);
-    return launch_lean_cfg<64, 8, 1>(p, stream);
+    if (p.flags & FRP_FLAG_F8) {                   // fp8 operands: whole 128-channel rows, 128-cout tiles only
+        if ((p.Cin & 127) || !p.wscale) return hipErrorInvalidValue;
+        return launch_lean_cfg<128, 4, 2, true>(p, stream);
+    }
+    if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false>(p, stream);
+    return launch_lean_cfg<64, 8, 1, false>(p, stream);
 }
 
 }  // namespace frp

@@ -563,6 +563,7 @@ bool conv3x3_rows_eligible(const ConvParams& p) {
 
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
+    if (p.out2) return launch_conv3x3_lean(p, stream);   // the fp8-copy epilogue lives in the static-loop generation only
     // dbg bits 2..5: timing-only ablations of the 128-cout kernel (wrong results; conv_bench only)
     if (p.Cout > 64) switch ((p.dbg >> 2) & 15) {
         case 1: return launch_rows_cfg<128, 4, 2, false, 1>(p, stream);

@@ -182,6 +182,130 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, floatx16 (&ac
 #undef FRP_EPI
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue with fp8 outputs (BASELINE config 5).  WS: the accumulator is first multiplied by lds_wscale[cout] (fp8
+// weights x fp8 input: per-cout weight scale x input-tensor scale).  Outputs: fp16 to p.out unless FRP_FLAG_OUT_FP8;
+// OCP E4M3 bytes (value / out_scale, clamped to +-448) to p.out when FRP_FLAG_OUT_FP8, else to p.out2 when set.
+// fp8 store layout: a lane packs its 4-cout runs into dwords, exchanges half-waves like the fp16 path and stores
+// 8 consecutive couts (8 bytes) per (32-cout block, half).
+__device__ __forceinline__ int pack_fp8x4(floatx4 v, float inv_scale) {
+    float a[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[e] * inv_scale, -448.f), 448.f);
+    int d = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], d, true);
+}
+
+template <int MP, int MC, int TC, bool FULL, int ACT, int RES, bool WS>
+__device__ __forceinline__ void conv_epilogue8_body(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
+                                                    const float* lds_bias, const float* lds_slope, const float* lds_wscale, int m0,
+                                                    int c0, int prow0, int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
+    const bool out8 = p.flags & FRP_FLAG_OUT_FP8;
+    unsigned char* dst8 = reinterpret_cast<unsigned char*>(out8 ? p.out : p.out2);
+    const float inv_os = 1.0f / p.out_scale;
+    const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
+    const int act = ACT < 0 ? p.act : ACT;
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const int mraw = m0 + prow0 + i * 32 + fr;
+        const bool mok = FULL || mraw < p.M;
+        const int m = mok ? mraw : 0;
+        int cls = 0;
+        if (border) {
+            int n, rem, oy, ox;
+            fast_divmod(m, HoWo, inv_howo, n, rem);
+            fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+            cls = ((oy == 0) ? 0 : (oy == p.Ho - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.Wo - 1) ? 2 : 1);
+        }
+        const long obase = (long)m * p.Cout;
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            half4 r4[4];
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    uint4 rr = rres[i][j][q];
+                    swap_halves(rr.x, rr.z);
+                    swap_halves(rr.y, rr.w);
+                    union { unsigned u[2]; half4 h; } lo, hi;
+                    lo.u[0] = rr.x; lo.u[1] = rr.y; hi.u[0] = rr.z; hi.u[1] = rr.w;
+                    r4[2 * q] = lo.h;
+                    r4[2 * q + 1] = hi.h;
+                }
+            }
+            floatx4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = crow0 + j * 32 + 8 * g + 4 * fh;
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls * TC + cl);
+                if constexpr (WS) {
+                    const floatx4 w4 = *reinterpret_cast<const floatx4*>(lds_wscale + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] * w4[e] + b4[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = acc[i][j][4 * g + e] + b4[e];
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] += (float)r4[g][e];
+                }
+                if (act == FRP_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                } else if (act == FRP_ACT_PRELU) {
+                    const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] > 0.f ? v[g][e] : v[g][e] * s4[e];
+                }
+            }
+            if (!out8) {                      // fp16 primary output
+                union { half4 h; unsigned u[2]; } pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[g][e];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                    swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                    if (FULL || (mok && co < p.Cout))
+                        *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(p.out) + obase + co) =
+                            make_uint4(pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]);
+                }
+            }
+            if (dst8) {                       // fp8 output (primary or copy)
+                unsigned d[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) d[g] = (unsigned)pack_fp8x4(v[g], inv_os);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    swap_halves(d[2 * q], d[2 * q + 1]);        // -> couts 16q + 8fh .. +7 of this pixel
+                    const int co = c0 + crow0 + j * 32 + 16 * q + 8 * fh;
+                    if (FULL || (mok && co < p.Cout))
+                        *reinterpret_cast<uint2*>(dst8 + obase + co) = make_uint2(d[2 * q], d[2 * q + 1]);
+                }
+            }
+        }
+    }
+}
+
+template <int MP, int MC, int TC, bool WS>
+__device__ __forceinline__ void conv_epilogue8(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
+                                               const float* lds_bias, const float* lds_slope, const float* lds_wscale, int m0, int c0,
+                                               int TP, int prow0, int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+#define FRP_EPI8(FULL_, ACT_, RES_) \
+    conv_epilogue8_body<MP, MC, TC, FULL_, ACT_, RES_, WS>(p, acc, rres, lds_bias, lds_slope, lds_wscale, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo)
+    const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
+    if (!full || !WS) { FRP_EPI8(false, -1, -1); return; }        // ragged tiles, and fp16 kernels that add an fp8 copy
+    const bool has_res = p.res != nullptr;
+    if (p.act == FRP_ACT_PRELU) { if (has_res) FRP_EPI8(true, FRP_ACT_PRELU, 1); else FRP_EPI8(true, FRP_ACT_PRELU, 0); }
+    else { if (has_res) FRP_EPI8(true, FRP_ACT_NONE, 1); else FRP_EPI8(true, -1, 0); }
+#undef FRP_EPI8
+}
+
 // residual of a tile in the STORE layout (16-byte chunks: couts 16q + 8*fh .. +7 of this lane's pixel), from clamped -
 // always valid - addresses; consumed by conv_epilogue
 template <int MP, int MC>

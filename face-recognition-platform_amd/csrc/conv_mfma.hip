@@ -383,7 +383,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
         {
             uint4 rres[MP][MC][2];
             if (has_res) conv_residual_loads<MP, MC>(p, rres, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
-            conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
+            if (p.out2)       // fp16 output plus an fp8 copy for an fp8 consumer (BASELINE config 5)
+                conv_epilogue8<MP, MC, TC, false>(p, acc, rres, lds_bias, lds_slope, lds_slope, m0, c0, TP, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
+            else
+                conv_epilogue<MP, MC, TC>(p, acc, rres, lds_bias, lds_slope, m0, c0, TP, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo);
         }
         if (ct == t0) stamp(p.stamps, 5);                      // first tile's epilogue issued
     }
@@ -439,8 +442,12 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if (p.ksplit > 1 && (p.nk % p.ksplit != 0 || !(p.flags & FRP_FLAG_OUT_F32) || p.res || (p.Cin & 63)))
         return hipErrorInvalidValue;             // split-K: exact slices, fp32 slabs, aligned path only
     // buffer descriptors carry 32-bit sizes and the kernel does signed 32-bit offset math
-    const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * p.Ktot * 2;
+    const bool f8 = (p.flags & FRP_FLAG_F8) != 0;
+    const int es = f8 ? 1 : 2;
+    const long xb = (long)p.N * p.H * p.W * p.Cin * es, wb = (long)p.Cout * p.Ktot * es;
     if (xb >= 0x7fffffffL || wb >= 0x7fffffffL) return hipErrorInvalidValue;
+    if ((p.flags & FRP_FLAG_OUT_FP8) && !f8) return hipErrorInvalidValue;
+    if ((p.out2 || f8) && ((p.flags & FRP_FLAG_OUT_F32) || p.ksplit > 1 || !(p.out_scale > 0.f))) return hipErrorInvalidValue;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
     const bool small = (p.Cin & 63) != 0;
@@ -455,6 +462,10 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if (!p.x || !p.w || !p.bias || !p.out) return hipErrorInvalidValue;
     if (p.act == FRP_ACT_PRELU && !p.slope) return hipErrorInvalidValue;
     // 3x3 stride-1 layers with whole 64-channel blocks: row-patch kernel (a third of the LDS-DMA traffic)
+    if (f8) {                                        // fp8 operands: only the static-loop row-patch kernel covers them
+        if (!conv3x3_rows_eligible(p) || (p.Cin & 127) || !p.wscale || !(p.in_scale > 0.f)) return hipErrorInvalidValue;
+        return launch_conv3x3_lean(p, stream);
+    }
     if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
     // Tile selection (measured on MI355X, tools/conv_bench.py):
     //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one

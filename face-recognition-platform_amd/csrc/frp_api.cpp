@@ -28,6 +28,7 @@ struct DevBuf {
 struct TensorDims {
     int h = 0, w = 0, c = 0;
     bool f32 = false;
+    bool f8 = false;      // OCP E4M3 bytes (BASELINE config 5: fp8 matrix path of the embedder)
 };
 
 struct Net {
@@ -192,14 +193,27 @@ int plan_net(frp_handle* h, Net& net, int batch, int H, int W, bool skip_input =
         out.f32 = (op.flags & FRP_FLAG_OUT_F32) != 0;
         if (out.h <= 0 || out.w <= 0) return fail(h, FRP_ERR_INVALID, "input too small for the network");
         if (in.f32) return fail(h, FRP_ERR_BLOB, "program reads an fp32 tensor as a conv input");
+        const bool op_f8 = (op.flags & FRP_OPFLAG_FP8_MFMA) != 0;
+        if (in.f8 != op_f8) return fail(h, FRP_ERR_BLOB, "program operand precision mismatch (fp8 op <-> fp8 tensor)");
+        if (op_f8 && !(op.ksize == 3 && op.stride == 1 && (op.cin & 127) == 0 && !(op.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_FLATTEN | FRP_FLAG_RES_UP2))))
+            return fail(h, FRP_ERR_BLOB, "op shape not covered by the fp8 matrix path");
+        out.f8 = (op.flags & FRP_OPFLAG_OUT_FP8) != 0;
+        if (out.f8 && (out.f32 || !op_f8)) return fail(h, FRP_ERR_BLOB, "fp8 primary output needs an fp8 op");
         if (op.res_buf >= 0) {                     // the epilogue reads the residual unchecked: validate it here
             const TensorDims& r = net.dims[op.res_buf];
             const bool up2 = (op.flags & FRP_FLAG_RES_UP2) != 0;
-            if (r.c != op.cout || r.f32 || (up2 ? (r.h * 2 != out.h || r.w * 2 != out.w) : (r.h != out.h || r.w != out.w)))
+            if (r.c != op.cout || r.f32 || r.f8 || (up2 ? (r.h * 2 != out.h || r.w * 2 != out.w) : (r.h != out.h || r.w != out.w)))
                 return fail(h, FRP_ERR_BLOB, "program residual shape mismatch");
         }
         net.dims[op.out_buf] = out;
-        need[op.out_buf] = std::max(need[op.out_buf], (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : 2));
+        need[op.out_buf] = std::max(need[op.out_buf], (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : out.f8 ? 1 : 2));
+        if (op.out2_buf >= 0) {                    // fp8 copy of an fp16 primary output
+            if (out.f32 || out.f8) return fail(h, FRP_ERR_BLOB, "fp8 copy of a non-fp16 output");
+            TensorDims o2 = out;
+            o2.f8 = true;
+            net.dims[op.out2_buf] = o2;
+            need[op.out2_buf] = std::max(need[op.out2_buf], (size_t)batch * out.h * out.w * out.c);
+        }
     }
     for (int i = 0; i < net.n_bufs; ++i)
         if (need[i]) FRPCHK(ensure(h, net.bufs[i], need[i]));
@@ -312,6 +326,16 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
         p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
         if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
+        p.in_scale = p.out_scale = 1.0f;
+        if (op.flags & FRP_OPFLAG_FP8_MFMA) {      // fp8 operands: E4M3 weights as stored, per-cout scales behind them
+            const size_t welems = (size_t)op.cout * op.ksize * op.ksize * op.cin;
+            p.flags |= FRP_FLAG_F8;
+            p.wscale = (const float*)(wbase + op.w_off + (welems + 15) / 16 * 16);
+            p.in_scale = op.in_scale;
+        }
+        if (op.flags & FRP_OPFLAG_OUT_FP8) p.flags |= FRP_FLAG_OUT_FP8;
+        if (op.out2_buf >= 0) p.out2 = net.bufs[op.out2_buf].p;
+        if ((op.flags & FRP_OPFLAG_OUT_FP8) || op.out2_buf >= 0) p.out_scale = op.out_scale;
         // skinny fp32-output GEMM (the FC): split K over the CUs; the slabs are reduced (+bias) by
         // the l2norm kernel that follows
         h->fc_ksplit = 0;
@@ -338,9 +362,13 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         out.w = (in.w + 2 * pad - op.ksize) / op.stride + 1;
         out.c = op.cout;
         out.f32 = (op.flags & FRP_FLAG_OUT_F32) != 0;
+        out.f8 = (op.flags & FRP_OPFLAG_OUT_FP8) != 0;
         d[op.out_buf] = out;
+        if (op.out2_buf >= 0) { TensorDims o2 = out; o2.f8 = true; d[op.out2_buf] = o2; }
         const int cin_r = op.real_ch & 0xffff, cout_r = (op.real_ch >> 16) & 0xffff;
-        *flops += 2.0 * batch * out.h * out.w * (double)op.ksize * op.ksize * (cin_r ? cin_r : op.cin) * (cout_r ? cout_r : op.cout);
+        const double fl = 2.0 * batch * out.h * out.w * (double)op.ksize * op.ksize * (cin_r ? cin_r : op.cin) * (cout_r ? cout_r : op.cout);
+        *flops += fl;
+        if (op.flags & FRP_OPFLAG_FP8_MFMA) { h->ctr.f8_conv_flops += fl; h->ctr.f8_conv_launches += 1; }
         *launches += 1;
     }
     net.dims = d;
@@ -363,6 +391,14 @@ int parse_net(frp_handle* h, const unsigned char* blob, size_t bytes, uint64_t o
             op.res_buf >= (int)n_bufs || op.res_buf < -1 || op.in_buf == op.out_buf || op.res_buf == op.out_buf)
             return fail(h, FRP_ERR_BLOB, "op buffer id out of range");
         if ((op.flags & FRP_FLAG_RES_UP2) && op.res_buf < 0) return fail(h, FRP_ERR_BLOB, "upsampled residual without a residual buffer");
+        if (op.out2_buf < -1 || op.out2_buf >= (int)n_bufs || op.out2_buf == op.in_buf || op.out2_buf == op.out_buf ||
+            (op.out2_buf >= 0 && op.out2_buf == op.res_buf))
+            return fail(h, FRP_ERR_BLOB, "op second-output buffer id out of range");
+        if ((op.flags & FRP_OPFLAG_FP8_MFMA) && !(op.flags & FRP_OPFLAG_W_FP8)) return fail(h, FRP_ERR_BLOB, "fp8 op without fp8 weights");
+        if ((op.flags & (FRP_OPFLAG_FP8_MFMA | FRP_OPFLAG_OUT_FP8)) || op.out2_buf >= 0) {
+            if (!(op.in_scale > 0.f) || !(op.out_scale > 0.f) || !std::isfinite(op.in_scale) || !std::isfinite(op.out_scale))
+                return fail(h, FRP_ERR_BLOB, "fp8 tensor scale must be positive and finite");
+        }
         if (!(op.ksize == 1 || op.ksize == 3) || !(op.stride == 1 || op.stride == 2) || op.cin < 8 || (op.cin & 7) ||
             op.cout < 4 || (op.cout & 3) || op.act < 0 || op.act > 2)
             return fail(h, FRP_ERR_BLOB, "op shape not supported");
@@ -817,12 +853,12 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
     size_t data_bytes = hd.data_bytes;
     bool any_fp8 = false;
     for (Net* net : {&h->det, &h->emb})
-        for (const frp_conv_op& op : net->ops) any_fp8 |= (op.flags & FRP_OPFLAG_W_FP8) != 0;
+        for (const frp_conv_op& op : net->ops) any_fp8 |= (op.flags & FRP_OPFLAG_W_FP8) && !(op.flags & FRP_OPFLAG_FP8_MFMA);
     if (any_fp8) {
         expanded.assign(data, data + hd.data_bytes);
         for (Net* net : {&h->det, &h->emb})
             for (frp_conv_op& op : net->ops) {
-                if (!(op.flags & FRP_OPFLAG_W_FP8)) continue;
+                if (!(op.flags & FRP_OPFLAG_W_FP8) || (op.flags & FRP_OPFLAG_FP8_MFMA)) continue;   // fp8 ops use the bytes as stored
                 const size_t per_row = (size_t)op.ksize * op.ksize * op.cin, n = per_row * op.cout;
                 const size_t src = (size_t)op.w_off, sc = src + (n + 15) / 16 * 16;
                 size_t dst = (expanded.size() + 255) / 256 * 256;
@@ -1387,6 +1423,58 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     return FRP_OK;
 }
 
+int frp_conv2d_f8(frp_handle* h, const void* x8, int32_t N, int32_t H, int32_t W, int32_t Cin, const void* w8, int32_t Cout,
+                  const float* wscale, const float* bias, const float* slope, const void* res16, int32_t act, int32_t flags,
+                  float in_scale, float out_scale, void* out, void* out2_f8) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!x8 || !w8 || !wscale || !bias || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0)
+        return fail(h, FRP_ERR_INVALID, "bad conv arguments");
+    const bool out8 = (flags & FRP_FLAG_OUT_FP8) != 0;
+    const size_t xb = (size_t)N * H * W * Cin, wb = (size_t)Cout * 9 * Cin, on = (size_t)N * H * W * Cout;
+    const size_t bb = (size_t)Cout * 4 * ((flags & FRP_FLAG_BORDER_BIAS) ? 9 : 1);
+    DevBuf dx, dw, dws, db, ds, dr, dout, dout2;
+    int rc = ensure(h, dx, xb);
+    if (rc == FRP_OK) rc = ensure(h, dw, wb);
+    if (rc == FRP_OK) rc = ensure(h, dws, (size_t)Cout * 4);
+    if (rc == FRP_OK) rc = ensure(h, db, bb);
+    if (rc == FRP_OK) rc = ensure(h, dout, on * (out8 ? 1 : 2));
+    if (rc == FRP_OK && out2_f8) rc = ensure(h, dout2, on);
+    if (rc == FRP_OK && slope) rc = ensure(h, ds, (size_t)Cout * 4);
+    if (rc == FRP_OK && res16) rc = ensure(h, dr, on * 2);
+    hipError_t e = hipSuccess;
+    if (rc == FRP_OK) {
+        e = hipMemcpyAsync(dx.p, x8, xb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dw.p, w8, wb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dws.p, wscale, (size_t)Cout * 4, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(db.p, bias, bb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && slope) e = hipMemcpyAsync(ds.p, slope, (size_t)Cout * 4, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && res16) e = hipMemcpyAsync(dr.p, res16, on * 2, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            ConvParams p{};
+            p.x = (const _Float16*)dx.p; p.w = (const _Float16*)dw.p; p.bias = (const float*)db.p;
+            p.slope = slope ? (const float*)ds.p : nullptr;
+            p.res = res16 ? (const _Float16*)dr.p : nullptr;
+            p.out = dout.p;
+            p.out2 = out2_f8 ? dout2.p : nullptr;
+            p.wscale = (const float*)dws.p;
+            p.in_scale = in_scale; p.out_scale = out_scale;
+            p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = 3; p.stride = 1; p.act = act;
+            p.flags = (flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_FP8)) | FRP_FLAG_F8;
+            e = launch_conv(p, h->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, on * (out8 ? 1 : 2), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && out2_f8) e = hipMemcpyAsync(out2_f8, dout2.p, on, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    DevBuf* all[] = {&dx, &dw, &dws, &db, &ds, &dr, &dout, &dout2};
+    for (DevBuf* b : all) release(*b);
+    if (rc != FRP_OK) return rc;
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("conv2d_f8: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("conv2d_f8 sync: ") + hipGetErrorString(e2));
+    return FRP_OK;
+}
+
 int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
                    int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg, uint64_t* stamps_out) {
     if (!h) return FRP_ERR_INVALID;
@@ -1502,7 +1590,9 @@ int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops) 
     release(dst);
     if (rc != FRP_OK) return rc;
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("kstep_lab: ") + hipGetErrorString(e));
-    *tflops = (float)((double)blocks * 8.0 * 16 * kstep_lab_steps_per_iter(variant) * iters * 32768.0 / (ms * 1e-3) / 1e12);
+    // fp8 variants (bit 10): 8 MFMAs of 32x32x64 per wave and step = twice the FLOPs of the fp16 step
+    *tflops = (float)((double)blocks * 8.0 * 16 * kstep_lab_steps_per_iter(variant) * iters * 32768.0 * ((variant & 1024) ? 2.0 : 1.0) /
+                      (ms * 1e-3) / 1e12);
     return FRP_OK;
 }
 

@@ -10,6 +10,8 @@
 #define FRP_FLAG_OUT_F32 2
 #define FRP_FLAG_RES_UP2 4
 #define FRP_FLAG_FLATTEN 8
+#define FRP_FLAG_F8 32          // conv on fp8 operands: input tensor and weights are OCP E4M3 bytes (blob: FRP_OPFLAG_FP8_MFMA)
+#define FRP_FLAG_OUT_FP8 64     // the primary output is fp8 (value / out_scale); an fp8 COPY of an fp16 output goes to `out2`
 #define FRP_CHIP_PIX (112 * 112)
 #ifndef FRP_MAX_FACES_CAP
 #define FRP_MAX_FACES_CAP 128
@@ -23,7 +25,11 @@ struct ConvParams {
     const float* bias;      // [Cout] or [9][Cout] (FRP_FLAG_BORDER_BIAS)
     const float* slope;     // [Cout] (PReLU) or null
     const _Float16* res;    // [N,Ho,Wo,Cout] (or [N,Hr,Wr,Cout] with FRP_FLAG_RES_UP2) or null
-    void* out;              // [N,Ho,Wo,Cout] fp16 (fp32 with FRP_FLAG_OUT_F32)
+    void* out;              // [N,Ho,Wo,Cout] fp16 (fp32 with FRP_FLAG_OUT_F32, fp8 with FRP_FLAG_OUT_FP8)
+    void* out2;             // optional fp8 copy of an fp16 output (value / out_scale), or null
+    const float* wscale;    // FRP_FLAG_F8: per-cout scale of the fp8 weights
+    float in_scale;         // FRP_FLAG_F8: the fp8 input tensor holds value / in_scale
+    float out_scale;        // fp8 outputs hold value / out_scale
     int N, H, W, Cin, Cout, KS, stride;
     int act, flags;
     int Hr, Wr;             // residual spatial dims (RES_UP2)

@@ -239,6 +239,84 @@ __global__ __launch_bounds__(512, 2) void kstep_lab16_kernel(const _Float16* __r
     dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The k-step on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, E4M3 operands, unit scales): the same LDS
+// image read as bytes - a 128-byte row is 128 k - so a step is 2 kk x (4 fragments of 32 B = 2 ds_read_b128 each) and
+// 8 MFMAs of 64 cycles: the LDS traffic and the matrix time of the fp16 step, twice its FLOPs.
+typedef int intx8 __attribute__((ext_vector_type(8)));
+template <int V>
+__global__ __launch_bounds__(512, 2) void kstep_lab8_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 384 * 128];
+    // fill with small-magnitude fp8 bit patterns (exponent field <= 8): no NaN codes, bounded sums
+    for (int i = threadIdx.x; i < 3 * 384 * 128 / 16; i += 512) {
+        uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        v.x &= 0xc7c7c7c7u; v.y &= 0xc7c7c7c7u; v.z &= 0xc7c7c7c7u; v.w &= 0xc7c7c7c7u;
+        reinterpret_cast<uint4*>(lds)[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int prow0 = (wave >> 1) * 64, crow0 = 256 + (wave & 1) * 64;
+    constexpr bool BAR = V & 1;
+    constexpr int P = (V >> 6) & 7;
+    floatx16 acc[2][2] = {};
+    intx8 f[2][4];
+    int addr[4][2][2];                    // [fragment][kk][half of the 32-byte fragment]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int row = (q < 2 ? prow0 + q * 32 : crow0 + (q - 2) * 32) + fr;
+                addr[q][kk][c] = row * 128 + (((4 * kk + 2 * fh + c) ^ ((row >> 1) & 7)) << 4);
+            }
+    auto rd = [&](int soff, int kk, int S) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(lds + soff + addr[q][kk][0]);
+            const uint4 hi = *reinterpret_cast<const uint4*>(lds + soff + addr[q][kk][1]);
+            f[S][q] = intx8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+    };
+    auto mm = [&](int S) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f[S][2 + j], f[S][i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4u << 20, 0x00020000);
+    unsigned goff = ((blockIdx.x * 8 + wave) * 8192u + lane * 16u) & ((4u << 20) - 1);
+    auto dma = [&](int slot, int piece) {
+        if constexpr (P > 0) {
+            dma16(rsrc, lds + slot * (384 * 128) + ((piece * 8 + wave) % 48) * 1024, goff);
+            goff = (goff + 1024u) & ((4u << 20) - 1);
+        }
+    };
+    if constexpr (P > 0) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) dma(1, q);
+#pragma unroll
+        for (int q = 0; q < P; ++q) dma(2, q);
+    }
+    int stage = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int soff = stage * (384 * 128);
+        const int wslot = stage == 0 ? 2 : stage - 1;
+        if constexpr (P > 0) wait_vmcnt<P>();
+        if constexpr (BAR) __builtin_amdgcn_s_barrier();
+        rd(soff, 0, 0);
+        rd(soff, 1, 1); mm(0);
+#pragma unroll
+        for (int q = 0; q < P; ++q) dma(wslot, q);
+        mm(1);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    float s = 0.f;
+    for (int e = 0; e < 16; ++e) s += acc[0][0][e] + acc[0][1][e] + acc[1][0][e] + acc[1][1][e];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int V>
 static void lab_launch(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream) {
     hipLaunchKernelGGL(kstep_lab_kernel<V>, dim3(blocks), dim3(512), 0, stream, src, dst, iters);
@@ -259,6 +337,9 @@ hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int var
 #define LAB16(v) case 512 + v: hipLaunchKernelGGL(kstep_lab16_kernel<v>, dim3(blocks), dim3(512), 0, stream, src, dst, iters); break;
         LAB16(0) LAB16(1) LAB16(5) LAB16(64 * 4 + 1) LAB16(64 * 4 + 5) LAB16(64 * 4 + 0)
 #undef LAB16
+#define LAB8(v) case 1024 + v: hipLaunchKernelGGL(kstep_lab8_kernel<v>, dim3(blocks), dim3(512), 0, stream, src, dst, iters); break;
+        LAB8(0) LAB8(1) LAB8(64 * 4 + 1) LAB8(64 * 4 + 0)
+#undef LAB8
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

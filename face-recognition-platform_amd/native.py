@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
-    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv2d_f8", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
 ]
 
 
@@ -43,7 +43,7 @@ class FrpCounters(C.Structure):
                 ("det_conv_flops", C.c_double), ("emb_conv_flops", C.c_double),
                 ("det_conv_launches", C.c_int64), ("emb_conv_launches", C.c_int64),
                 ("match_bytes", C.c_double), ("match_launches", C.c_int64), ("gallery_rows", C.c_int64),
-                ("reserved", C.c_double * 8)]
+                ("f8_conv_flops", C.c_double), ("f8_conv_launches", C.c_int64), ("reserved", C.c_double * 6)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("reserved", "struct_size")}
@@ -119,6 +119,7 @@ def load_library() -> C.CDLL:
     lib.frp_match.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.frp_match_scores.argtypes = [vp, vp, i32, vp, i64]
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.frp_conv2d_f8.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]
     lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
     lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_kstep_lab.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
@@ -418,6 +419,26 @@ class Engine:
         self._chk(self._lib.frp_conv2d_nhwc(self._h, _ptr(x), N, H, W, Cin, _ptr(w), Cout, k, stride, _ptr(bias), _ptr(slope),
                                             _ptr(res), rh, rw, act, flags, _ptr(out)))
         return out
+
+    def conv2d_f8(self, x8, w8, wscale, bias, act=0, slope=None, res=None, flags=0, in_scale=1.0, out_scale=1.0,
+                  out_fp8=False, copy_fp8=False):
+        """3x3 stride-1 conv on E4M3 operands (uint8 codes).  -> fp16 output (or uint8 codes with out_fp8), plus the
+        uint8 copy with copy_fp8"""
+        x8 = np.ascontiguousarray(x8, dtype=np.uint8)
+        w8 = np.ascontiguousarray(w8, dtype=np.uint8)
+        N, H, W, Cin = x8.shape
+        Cout = w8.shape[0]
+        wscale = np.ascontiguousarray(wscale, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        if slope is not None:
+            slope = np.ascontiguousarray(slope, dtype=np.float32)
+        if res is not None:
+            res = np.ascontiguousarray(res, dtype=np.float16)
+        out = np.empty((N, H, W, Cout), np.uint8 if out_fp8 else np.float16)
+        out2 = np.empty((N, H, W, Cout), np.uint8) if copy_fp8 else None
+        self._chk(self._lib.frp_conv2d_f8(self._h, _ptr(x8), N, H, W, Cin, _ptr(w8), Cout, _ptr(wscale), _ptr(bias), _ptr(slope),
+                                          _ptr(res), act, flags | (64 if out_fp8 else 0), in_scale, out_scale, _ptr(out), _ptr(out2)))
+        return (out, out2) if copy_fp8 else out
 
     def conv_bench(self, N, H, W, Cin, Cout, k=3, stride=1, act=0, flags=0, with_res=False, iters=20, stamps=False):
         ms = C.c_float()

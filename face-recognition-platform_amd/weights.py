@@ -24,12 +24,14 @@ from . import netspec as ns
 
 BN_EPS = 1e-5
 BLOB_MAGIC = b"FRPBLOB1"
-BLOB_VERSION = 1
+BLOB_VERSION = 2
 HEADER_FMT = "<8sII" + "IIII" + "III" + "I" + "IIII" + "IIII" + "QQQQ" + "QQ"
 HEADER_BYTES = struct.calcsize(HEADER_FMT)
-OP_FMT = "<iiiiiiiiiiqqq"
+OP_FMT = "<iiiiiiiiiiqqqiffi"
+OP_FIELDS = ["in_buf", "out_buf", "res_buf", "cin", "cout", "ksize", "stride", "act", "flags", "real_ch", "w_off", "bias_off",
+             "slope_off", "out2_buf", "in_scale", "out_scale", "reserved"]
 OP_BYTES = struct.calcsize(OP_FMT)
-assert HEADER_BYTES == 128 and OP_BYTES == 64
+assert HEADER_BYTES == 128 and OP_BYTES == 80
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -161,6 +163,8 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
         last_use[l.src] = i
         if l.res:
             last_use[l.res] = i
+        if getattr(l, "dst2", None):
+            last_use.setdefault(l.dst2, i)          # a copy nobody reads still needs a buffer while it is written
     phys: Dict[str, int] = {}
     free: List[int] = []
     n = 0
@@ -168,14 +172,15 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
         phys[p] = n
         n += 1
     for i, l in enumerate(layers):
-        if l.dst not in phys:
-            if free:
-                phys[l.dst] = free.pop(0)
-            else:
-                phys[l.dst] = n
-                n += 1
+        for d in (l.dst, getattr(l, "dst2", None)):
+            if d and d not in phys:
+                if free:
+                    phys[d] = free.pop(0)
+                else:
+                    phys[d] = n
+                    n += 1
         # release tensors whose last use is this op (after allocating dst: in/out never alias)
-        for t in {l.src, l.res}:
+        for t in {l.src, l.res, getattr(l, "dst2", None)}:
             if t and t not in pinned and last_use.get(t) == i and t in phys:
                 free.append(phys[t])
     return phys, n
@@ -183,6 +188,34 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
 
 # ---------------------------------------------------------------------------- fp8 weight storage (BASELINE config 5)
 OPFLAG_W_FP8 = 16          # include/frp_blob.h: FRP_OPFLAG_W_FP8
+OPFLAG_FP8_MFMA = 32       # FRP_OPFLAG_FP8_MFMA
+OPFLAG_OUT_FP8 = 64        # FRP_OPFLAG_OUT_FP8
+
+
+def fp8_mfma_eligible(l: ns.ConvLayer) -> bool:
+    """convs the fp8 matrix path covers: 3x3 stride 1 over whole 128-channel rows, fp16/fp8 outputs (the bulk of
+    IResNet stages 2-4: every conv1 / conv2 except the strided conv2 and the 64 -> 128 conv1 of stage 2)"""
+    return (l.k == 3 and l.stride == 1 and l.cin % 128 == 0 and l.cout % 8 == 0 and l.cin_real is None and
+            not (l.flags & (ns.FLAG_OUT_F32 | ns.FLAG_FLATTEN | ns.FLAG_RES_UP2)))
+
+
+def plan_fp8(layers: List[ns.ConvLayer]):
+    """Which ops run on fp8 operands and which tensors exist in which precision.  -> per layer dict(f8, out8, dst2):
+    f8: the op reads the fp8 copy of its input (tensor name + "@8"); out8: its primary output is fp8 (every consumer is an
+    fp8 op and nobody needs it as a residual); dst2: name of the fp8 copy it writes next to its fp16 output."""
+    elig = [fp8_mfma_eligible(l) for l in layers]
+    need8, need16 = set(), set()
+    for l, e in zip(layers, elig):
+        (need8 if e else need16).add(l.src)
+        if l.res:
+            need16.add(l.res)
+    need16.add(layers[-1].dst)
+    plan = []
+    for l, e in zip(layers, elig):
+        out8 = e and l.dst in need8 and l.dst not in need16
+        dst2 = (l.dst + "@8") if (l.dst in need8 and not out8) else None
+        plan.append({"f8": e, "out8": out8, "dst2": dst2})
+    return plan
 
 
 def _fp8_e4m3_table() -> np.ndarray:
@@ -236,8 +269,8 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
     """weight_format "fp8": conv/FC weights are stored as E4M3 bytes + one fp32 scale per output channel
     (half the blob, half the upload); the library expands them to fp16 at load, the kernels are the fp16
     ones.  `w16_hook(layer, w16) -> w16` lets tests substitute the folded fp16 weights of a layer."""
-    if weight_format not in ("fp16", "fp8"):
-        raise ValueError("weight_format must be 'fp16' or 'fp8'")
+    if weight_format not in ("fp16", "fp8", "fp8-mfma"):
+        raise ValueError("weight_format must be 'fp16', 'fp8' (storage only) or 'fp8-mfma' (fp8 storage + fp8 matrix path for the embedder)")
     det = ns.detector_layers(det_blocks)
     emb = ns.iresnet_layers(emb_blocks)
     data = bytearray()
@@ -249,15 +282,28 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
         data.extend(np.ascontiguousarray(arr).tobytes())
         return off
 
-    def pack_ops(layers, pinned):
-        phys, nb = assign_buffers(layers, pinned)
+    def pack_ops(layers, pinned, fp8_mfma=False):
+        import copy
+        plan = plan_fp8(layers) if fp8_mfma else [{"f8": False, "out8": False, "dst2": None}] * len(layers)
+        view = []                                   # the layer list as the buffer planner sees it (fp8 tensors by name)
+        for l, pl in zip(layers, plan):
+            v = copy.copy(l)
+            if pl["f8"]:
+                v.src = l.src + "@8" if not any(q["out8"] and ll.dst == l.src for ll, q in zip(layers, plan)) else l.src
+            v.dst2 = pl["dst2"]
+            view.append(v)
+        phys, nb = assign_buffers(view, pinned)
         ops = bytearray()
-        for l in layers:
+        for l, v, pl in zip(layers, view, plan):
             w16, bias, slope = fold_layer(raw, l)
             if w16_hook is not None:
                 w16 = w16_hook(l, w16)
             flags = l.flags
-            if weight_format == "fp8":
+            if pl["f8"]:
+                flags |= OPFLAG_FP8_MFMA
+            if pl["out8"]:
+                flags |= OPFLAG_OUT_FP8
+            if weight_format in ("fp8", "fp8-mfma"):
                 codes, scale = fp8_quantize_rows(w16)
                 w_off = put(codes)
                 data.extend(b"\0" * ((-len(data)) % 16))
@@ -267,13 +313,14 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
                 w_off = put(w16)
             b_off = put(bias)
             s_off = put(slope) if slope is not None else -1
-            ops += struct.pack(OP_FMT, phys[l.src], phys[l.dst], phys[l.res] if l.res else -1,
+            ops += struct.pack(OP_FMT, phys[v.src], phys[l.dst], phys[l.res] if l.res else -1,
                                l.cin, l.cout, l.k, l.stride, l.act, flags,
-                               (l.cin_real or l.cin) | ((l.cout_real or l.cout) << 16), w_off, b_off, s_off)
+                               (l.cin_real or l.cin) | ((l.cout_real or l.cout) << 16), w_off, b_off, s_off,
+                               phys[v.dst2] if v.dst2 else -1, 1.0, 1.0, 0)
         return bytes(ops), phys, nb
 
     det_ops, det_phys, det_nb = pack_ops(det, ["det.in", "det.out3", "det.out4", "det.out5"])
-    emb_ops, emb_phys, emb_nb = pack_ops(emb, ["emb.in", "emb.out"])
+    emb_ops, emb_phys, emb_nb = pack_ops(emb, ["emb.in", "emb.out"], fp8_mfma=(weight_format == "fp8-mfma"))
     det_macs, _ = ns.layer_macs(det, 1088, 1920, "det.in")
     emb_macs, _ = ns.layer_macs(emb, ns.EMB_SIZE, ns.EMB_SIZE, "emb.in")
     det_ops_off = HEADER_BYTES

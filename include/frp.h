@@ -78,7 +78,9 @@ typedef struct frp_counters {
     double match_bytes;       /* algorithmic gallery bytes streamed by the match kernel */
     int64_t match_launches;
     int64_t gallery_rows;
-    double reserved[8];
+    double f8_conv_flops;     /* part of det/emb_conv_flops that ran on fp8 operands (BASELINE config 5) */
+    int64_t f8_conv_launches;
+    double reserved[6];
 } frp_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------
@@ -199,6 +201,14 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
                     const void* w, int32_t Cout, int32_t ksize, int32_t stride,
                     const float* bias, const float* slope, const void* res, int32_t res_h, int32_t res_w,
                     int32_t act, int32_t flags, void* out);
+
+/* one 3x3 stride-1 convolution on fp8 operands through the block-scaled fp8 MFMA kernel (BASELINE config 5; kernel parity
+ * tests): x8 [N,H,W,Cin] and w8 [Cout][3][3][Cin] are OCP E4M3 bytes (Cin a multiple of 128), value = code * scale with
+ * one scale per output channel (wscale) and one for the input tensor (in_scale); res16 fp16 or NULL; `out` fp16, or E4M3
+ * bytes (value / out_scale) with FRP_FLAG_OUT_FP8 = 64 in `flags`; out2_f8: optional E4M3 copy of an fp16 output */
+int frp_conv2d_f8(frp_handle* h, const void* x8, int32_t N, int32_t H, int32_t W, int32_t Cin, const void* w8, int32_t Cout,
+                  const float* wscale, const float* bias, const float* slope, const void* res16, int32_t act, int32_t flags,
+                  float in_scale, float out_scale, void* out, void* out2_f8);
 
 /* tuning hook: average milliseconds of `iters` back-to-back launches of one conv shape on
  * random device-resident operands (HIP events on the handle's stream) */

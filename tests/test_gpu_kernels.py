@@ -443,3 +443,53 @@ def test_embedder_large_batch_equals_small_batch_and_oracle(engine):
     ref = onet.emb_forward(raw, onet.emb_blob(chips[pick]))
     assert (small * ref).sum(1).min() > 1 - 1e-3
     assert np.abs(np.linalg.norm(big, axis=1) - 1).max() < 1e-4
+
+
+F8_CASES = [
+    # N, H, W, Cin, Cout, act, res, flags(border), out_fp8, copy_fp8
+    (2, 14, 14, 128, 128, 2, False, 1, True, False),     # conv1 of an IResNet block: PReLU + border bias, fp8 out
+    (3, 14, 14, 256, 256, 0, True, 0, False, True),      # conv2: residual, fp16 out + fp8 copy, two channel blocks, two cout tiles
+    (1, 7, 7, 512, 512, 2, False, 1, True, False),       # 4 channel blocks, 4 cout tiles, ragged pixel tile
+    (5, 28, 28, 128, 128, 0, True, 0, False, True),      # several pixel tiles
+    (1, 5, 9, 128, 96, 1, False, 0, False, False),       # ragged cout tile, fp16 out only
+]
+
+
+@pytest.mark.parametrize("case", F8_CASES)
+def test_conv_fp8_mfma_parity(engine, case):
+    """BASELINE config 5: the block-scaled fp8 MFMA conv (v_mfma_scale_f32_32x32x64_f8f6f4, E4M3 operands, unit block
+    scales) against an fp32 reference on the DEQUANTISED operands.  Products of two E4M3 values are exact in fp32, so
+    the two differ by fp32 summation order only: fp16 outputs to output rounding (2e-3 of the scale), fp8 outputs to
+    the same E4M3 code except where the value sits on a rounding boundary (<= 1 code step, rarely)."""
+    from frp_amd import weights as wts
+    N, H, W, Cin, Cout, act, has_res, flags, out8, copy8 = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    xq = wts.fp8_e4m3_encode(rng.standard_normal((N, H, W, Cin)).astype(np.float32))
+    x = wts.FP8_E4M3[xq]
+    w16 = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
+    wq, wscale = wts.fp8_quantize_rows(w16)
+    wq = wq.reshape(Cout, 3, 3, Cin)
+    wdq = wts.FP8_E4M3[wq] * wscale[:, None, None, None]
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
+    in_scale, out_scale = 0.5, 0.25
+    got = engine.conv2d_f8(xq, wq, wscale, bias, act=act, slope=slope, res=res, flags=flags, in_scale=in_scale,
+                           out_scale=out_scale, out_fp8=out8, copy_fp8=copy8)
+    ref = _conv_ref((x * in_scale).astype(np.float32), wdq.astype(np.float32), bias, 1, act, slope, res, flags)
+    scale = max(1.0, float(np.abs(ref).max()))
+
+    def check_fp8(codes):
+        want = wts.fp8_e4m3_encode(np.clip(ref / out_scale, -448, 448))
+        gv, wv = wts.FP8_E4M3[codes], wts.FP8_E4M3[want]
+        assert np.mean(codes == want) > 0.995
+        step = np.maximum(np.abs(wv), 2.0 ** -6) * 2.0 ** -3        # one E4M3 code step at the value's binade
+        assert np.all(np.abs(gv - wv) <= step)
+
+    if out8:
+        check_fp8(got)
+    else:
+        out16, out2 = got if copy8 else (got, None)
+        assert np.abs(out16.astype(np.float32) - ref).max() <= 2e-3 * scale
+        if copy8:
+            check_fp8(out2)

@@ -25,6 +25,8 @@ def main():
             label += f"+dma{(v >> 6) & 7}"
         if v & 512:
             label += " [16x16x32]"
+        if v & 1024:
+            label += " [fp8 32x32x64 scaled]"
         print(f"variant {v:3d} {label:24s} {best[v]:8.1f} TF")
 
 
