@@ -1485,6 +1485,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t xn = (size_t)N * H * W * Cin, wn = (size_t)Cout * ksize * ksize * Cin, on = (size_t)N * Ho * Wo * Cout;
+    const bool f8 = (flags & FRP_FLAG_F8) != 0;          // fp8 operands: random fp16 bit patterns read as E4M3 bytes (timing only)
     DevBuf dx, dw, db, ds, dr, dout;
     int rc = ensure(h, dx, xn * 2);
     if (rc == FRP_OK) rc = ensure(h, dw, wn * 2);
@@ -1504,7 +1505,13 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         p.x = (const _Float16*)dx.p; p.w = (const _Float16*)dw.p; p.bias = (const float*)db.p; p.slope = (const float*)ds.p;
         p.res = with_res ? (const _Float16*)dr.p : nullptr; p.out = dout.p;
         p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
-        p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32);
+        p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8);
+        if (f8) {                                         // unit scales in the slope buffer's neighbour: reuse the bias buffer (zeros) + 1
+            p.wscale = (const float*)ds.p;                // zeros: products vanish, timing is unaffected
+            p.in_scale = p.out_scale = 1.0f;
+            if (!(flags & FRP_FLAG_OUT_FP8)) p.out2 = dr.p;   // conv2-style: fp16 out + fp8 copy (residual buffer doubles as the copy target when unused)
+            if (with_res) p.out2 = nullptr;
+        }
         p.dbg = (flags >> 8) & 0xff;
         DevBuf dst;
         if (stamps_out && ensure(h, dst, 256 * 8 * 8) == FRP_OK) {
