@@ -24,7 +24,13 @@ namespace frp {
 #define NT 1024
 
 __device__ __forceinline__ unsigned sortable16(unsigned short h) {
+    if ((h & 0x7fffu) > 0x7c00u) return 0u;     // NaN (real fp16 weights can overflow a head): the lowest key, below -inf
     return (h & 0x8000u) ? (unsigned)(unsigned short)(~h) : (unsigned)(h | 0x8000u);
+}
+// candidate test: logit >= threshold; in forced top-K mode (threshold -inf) EVERY anchor is a candidate, NaN logits
+// included (they sort last), so exactly min(K, anchors) faces come out and the compact face list never runs short
+__device__ __forceinline__ bool is_candidate(_Float16 lg, float lt) {
+    return lt == -INFINITY ? true : (float)lg >= lt;
 }
 
 // scalar members + select chains (runtime-indexed arrays would live in scratch)
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
     __syncthreads();
     const _Float16* dense = p.logits + (long)b * A;     // written by gather_logits_kernel
     int local = 0;
-    for (int i = tid; i < A; i += NT) local += ((float)dense[i] >= lt) ? 1 : 0;
+    for (int i = tid; i < A; i += NT) local += is_candidate(dense[i], lt) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     if ((tid & 63) == 0) atomicAdd(&s_cnt, local);
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
             __syncthreads();
             for (int i = tid; i < A; i += NT) {
                 const _Float16 lg = dense[i];
-                if ((float)lg >= lt) {
+                if (is_candidate(lg, lt)) {
                     const unsigned long long k = ((unsigned long long)sortable16(__builtin_bit_cast(unsigned short, lg)) << 20) |
                                                  (unsigned long long)(0xFFFFF - i);
                     if (pass == 0 || (k >> (shift + 12)) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xFFF)], 1);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NT) void decode_nms_kernel(DecodeParams p) {
     __syncthreads();
     for (int i = tid; i < A; i += NT) {
         const _Float16 lg = dense[i];
-        if ((float)lg >= lt) {
+        if (is_candidate(lg, lt)) {
             const unsigned long long k = ((unsigned long long)sortable16(__builtin_bit_cast(unsigned short, lg)) << 20) |
                                          (unsigned long long)(0xFFFFF - i);
             if (k >= T) {

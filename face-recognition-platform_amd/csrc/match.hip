@@ -9,8 +9,9 @@
 // HBM layout: gallery [N][512] fp16 row-major, streamed exactly once per pass; queries
 // [Mpad][512] fp16 (L2-resident).  A workgroup owns 128 gallery rows: each of its 4 waves
 // loads 32 rows x 512 k straight into registers as 32 MFMA A-fragments (all 32 loads in
-// flight at once = 32 KiB per wave), then walks the query tiles (32 queries each, staged in a
-// swizzled, double-buffered LDS image) with v_mfma_f32_32x32x16_f16 and reduces the 32x32
+// flight at once = 32 KiB per wave), then walks the query tiles (32 queries each, staged by LDS-DMA in a
+// swizzled LDS image: two separate buffers, the DMA of tile t+1 issued before the MFMAs of tile t and waited
+// for - s_waitcnt vmcnt(0) - only after them) with v_mfma_f32_32x32x16_f16 and reduces the 32x32
 // score tile to a running (max, argmin-index-on-ties) per query.  Per-workgroup partial
 // winners go to HBM and a second tiny kernel reduces them.  Algorithmic bytes = N*512*2.
 #include <hip/hip_runtime.h>
@@ -31,7 +32,10 @@ __device__ __forceinline__ int q_lds_off(int row, int chunk) {   // 1 KiB rows, 
 }
 
 __global__ __launch_bounds__(256, 2) void match_kernel(MatchParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char qs[2][MT_Q * 1024];
+    // two DISTINCT arrays: with one runtime-indexed array the compiler cannot tell the DMA target from the tile being
+    // read and waits for the prefetch (vmcnt(0)) before the first fragment read of every tile
+    __shared__ __attribute__((aligned(16))) unsigned char qs0[MT_Q * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char qs1[MT_Q * 1024];
     __shared__ float red_cos[4][MT_Q];
     __shared__ int red_idx[4][MT_Q];
 
@@ -54,29 +58,38 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchParams p) {
     // query tile staging by LDS-DMA (no staging VGPRs: the 128 fragment registers stay resident).
     // One wave-instruction writes one 1-KiB row linearly (lane L -> chunk position L), so the
     // bank swizzle is applied on the per-lane SOURCE address: position L holds chunk L ^ (row&15).
-    auto q_dma = [&](int qt, int buf) {
+    auto q_dma = [&](int qt, unsigned char* buf) {
         const _Float16* qp = p.q + (long)qt * MT_Q * MD;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = wave * 8 + i;
             const _Float16* src = qp + (long)row * MD + ((lane ^ (row & 15)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)&qs[buf][row * 1024], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(buf + row * 1024), 16, 0, 0);
         }
     };
-    q_dma(0, 0);
-    __syncthreads();
+    q_dma(0, qs0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     for (int qt = 0; qt < nqt; ++qt) {
-        const int cur = qt & 1;
-        if (qt + 1 < nqt) q_dma(qt + 1, cur ^ 1);
+        const bool odd = qt & 1;
+        if (qt + 1 < nqt) { if (odd) q_dma(qt + 1, qs0); else q_dma(qt + 1, qs1); }
         floatx16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (odd) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const half8 qf = *reinterpret_cast<const half8*>(&qs[cur][q_lds_off(fr, 2 * s + fh)]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf[s], qf, acc, 0, 0, 0);
+            for (int s = 0; s < 32; ++s) {
+                const half8 qf = *reinterpret_cast<const half8*>(&qs1[q_lds_off(fr, 2 * s + fh)]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf[s], qf, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const half8 qf = *reinterpret_cast<const half8*>(&qs0[q_lds_off(fr, 2 * s + fh)]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf[s], qf, acc, 0, 0, 0);
+            }
         }
         // acc[e]: gallery row (e&3) + 8*(e>>2) + 4*fh of this wave's 32, query column fr
         const int q = qt * MT_Q + fr;
@@ -111,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchParams p) {
             p.part_cos[o] = bc;
             p.part_idx[o] = bi;
         }
-        __syncthreads();
+        // the next tile's DMA (issued before this tile's MFMAs) has had the whole tile to land
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 

@@ -149,8 +149,9 @@ def decode_nms(head_maps: Sequence[np.ndarray], score_thresh: float, nms_iou: fl
     cy = np.concatenate(cys)
     st = np.concatenate(strs)
     lt = logit_threshold(score_thresh)
-    cand = np.nonzero(logit >= lt)[0]
-    order = cand[np.argsort(-logit[cand], kind="stable")]  # desc logit, ties by anchor index asc
+    # forced top-K mode (threshold <= 0, i.e. -inf): every anchor is a candidate, NaN logits included - they sort last
+    cand = np.arange(len(logit)) if np.isneginf(lt) else np.nonzero(logit >= lt)[0]
+    order = cand[np.argsort(-logit[cand], kind="stable")]  # desc logit (NaN last), ties by anchor index asc
     order = order[:cap]
     v = vals[order]
     s = st[order]

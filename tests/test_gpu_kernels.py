@@ -197,6 +197,29 @@ def test_decode_nms_parity(engine, Hc, Wc, thresh, forced, shift):
         assert np.all(o["boxes"][b, n:] == 0) and np.all(o["anchor_idx"][b, n:] == -1)
 
 
+def test_decode_forced_k_with_nan_and_inf_logits(engine):
+    """forced top-K keeps exactly K anchors whatever the head produced: +inf first, NaN logits last (a defined lowest
+    key), so the compact face list the embedder walks never runs short (real fp16 weights can overflow a head)"""
+    rng = np.random.default_rng(3)
+    heads = _random_heads(rng, 1, 64, 64)
+    h0 = heads[0]
+    h0[0, :, :, 0] = np.nan                    # all first-anchor logits of the finest level: NaN
+    h0[0, 2, 3, 15] = np.inf
+    heads[1][0, :, :, 0] = -np.inf
+    K = 20
+    o = engine.decode_heads(heads, (64, 64), max_faces=K, det_thresh=0.5, nms_iou=0.4, flags=1)
+    ob, ok, osc, oa = onet.decode_nms([h[0] for h in heads], 0.0, 2.0, K)
+    assert o["counts"][0] == K == len(oa)
+    assert np.array_equal(o["anchor_idx"][0], oa)
+    assert oa[0] == 2 * (2 * 8 + 3) + 1        # the +inf anchor leads
+    # every anchor NaN: still K faces, in anchor order
+    for h in heads:
+        h[..., 0] = np.nan
+        h[..., 15] = np.nan
+    o = engine.decode_heads(heads, (64, 64), max_faces=K, det_thresh=0.5, nms_iou=0.4, flags=1)
+    assert o["counts"][0] == K and np.array_equal(o["anchor_idx"][0], np.arange(K))
+
+
 def test_decode_ties_by_anchor_index(engine):
     heads = [np.zeros((1, 64 // s, 64 // s, 32), np.float16) for s in (8, 16, 32)]
     for h in heads:
