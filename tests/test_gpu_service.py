@@ -239,3 +239,43 @@ def test_locations_are_proper_boxes_with_planted_head_weights(engine, monkeypatc
     assert np.mean(d.min(1) <= 0.5) >= 0.8
     raw2, blob2 = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
     engine.load_weights(blob2)
+
+
+def test_staged_ingest_of_encoded_stills(engine, tmp_path):
+    """f-4 (first step): PNG / JPEG uploads decoded into the engine's page-locked staging and processed with the copy of
+    batch t+1 under the compute of batch t: same results as handing the decoded arrays to process_frames."""
+    from PIL import Image
+    from frp_amd import native
+    from frp_amd.ingest import StagedIngest
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(21)
+    engine.gallery_set(rng.standard_normal((300, 512)).astype(np.float32))
+    H, W, B = 96, 128, 3
+    stills, batches = [], []
+    for i in range(7):
+        img = np.clip(rng.normal(120, 35, (H, W, 3)), 0, 255).astype(np.uint8)
+        if i % 2:
+            p = str(tmp_path / f"s{i}.png")
+            Image.fromarray(img).save(p)
+            src = p
+        else:
+            b = __import__("io").BytesIO()
+            Image.fromarray(img).save(b, format="PNG")
+            src = b.getvalue()
+        stills.append(img)
+        if i % B == 0:
+            batches.append([])
+        batches[-1].append(src)
+    ing = StagedIngest(engine, B, H, W)
+    got = list(ing.run(batches, max_faces=4, flags=native.FLAG_FORCED_K))
+    assert [n for n, _ in got] == [3, 3, 1]
+    k = 0
+    for n, out in got:
+        ref = engine.process_frames(np.stack(stills[k:k + n]), max_faces=4, flags=native.FLAG_FORCED_K | native.FLAG_RGB)
+        for key in ("boxes", "kps", "emb", "match_idx", "match_cos", "counts"):
+            assert np.array_equal(out[key][:n], ref[key]), key
+        k += n
+    with pytest.raises(ValueError):
+        ing.decode_into(0, [np.zeros((10, 10, 3), np.uint8)])
+    engine.gallery_set(np.zeros((0, 512), np.float32))
