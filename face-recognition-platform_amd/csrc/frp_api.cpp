@@ -75,6 +75,7 @@ struct frp_handle {
     int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them
     const float* fc_bias = nullptr;
     int last_B = 0, last_K = 0, last_nfaces = 0;
+    bool ev_pending = false;   // frp_process_resident's stage events are recorded but not yet read (see settle_events)
     bool last_matched = false;
     int32_t* h_nfaces = nullptr;   // pinned
     unsigned char* pin_stage = nullptr;   // pinned staging of the result fetch
@@ -648,6 +649,17 @@ void accumulate_face_events(frp_handle* h) {
     h->ctr.ms_total += el(EV_DEC, EV_MATCH);
 }
 
+// frp_process_resident returns without waiting for the device also when the stage timers are on: its events are read
+// by whichever entry point next waits for the stream anyway (frp_fetch_results, frp_synchronize), or - with a wait of
+// their own - by the first other call on the handle, before it could re-record them.  (Reading them inside
+// frp_process_resident cost a full stream drain per step: 0.8 ms of a 15 ms step in bench.py's fetch-every-step loop.)
+void settle_events(frp_handle* h, bool stream_is_idle) {
+    if (!h->ev_pending) return;
+    h->ev_pending = false;
+    if (!stream_is_idle && hipStreamSynchronize(h->stream) != hipSuccess) return;
+    accumulate_events(h, false);
+}
+
 // page-locked staging for the result fetch, grown on demand.  Device -> PAGEABLE host copies go through the runtime's own
 // bounce buffers with whole-device synchronisation semantics: next to torch / RCCL in the process they serialised the
 // copy stream's upload of the next batch behind the fetch (the overlapped loop lost its overlap: 20 vs 14.7 ms per
@@ -693,6 +705,7 @@ int fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_
         HIPCHK(h, hipMemcpyAsync(st + o_cos, h->best_cos.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    settle_events(h, true);
     const int32_t* cnt = (const int32_t*)(st + o_cnt);
     if (counts) memcpy(counts, cnt, (size_t)B * 4);
     if (boxes) memcpy(boxes, st + o_box, s * 16);
@@ -753,7 +766,10 @@ int upload_rows_normalized(frp_handle* h, const float* rows, int64_t n, _Float16
 
 struct Guard {
     std::lock_guard<std::mutex> lk;
-    explicit Guard(frp_handle* h) : lk(h->mu) { (void)hipSetDevice(h->device); }
+    explicit Guard(frp_handle* h, bool settle = true) : lk(h->mu) {
+        (void)hipSetDevice(h->device);
+        if (settle) settle_events(h, false);
+    }
 };
 
 }  // namespace
@@ -1046,25 +1062,23 @@ int frp_process_resident(frp_handle* h, int32_t max_faces, float det_thresh, flo
     Guard g(h);
     rec(h, EV_H2D);
     FRPCHK(run_pipeline(h, max_faces, det_thresh, nms_iou, flags));
-    if (h->cfg.profile) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        accumulate_events(h, false);
-    }
+    h->ev_pending = h->cfg.profile != 0;
     h->ctr.calls += 1;
     return FRP_OK;
 }
 
 int frp_synchronize(frp_handle* h) {
     if (!h) return FRP_ERR_INVALID;
-    Guard g(h);
+    Guard g(h, false);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    settle_events(h, true);
     return FRP_OK;
 }
 
 int frp_fetch_results(frp_handle* h, int32_t B, int32_t max_faces, float* boxes, float* kps, float* scores, int32_t* counts,
                       float* emb, int32_t* match_idx, float* match_cos) {
     if (!h) return FRP_ERR_INVALID;
-    Guard g(h);
+    Guard g(h, false);
     // the caller sized its buffers for B x max_faces: refuse when another thread's call on this handle changed
     // the shape of the results in between (checked under the handle mutex)
     if (B != h->last_B || max_faces != h->last_K)
