@@ -298,11 +298,12 @@ def test_blob_layout_and_buffer_liveness():
     raw = weights.make_synthetic_raw(7, (1, 1, 1, 1), (1, 1, 1, 1))
     blob = weights.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1))
     hdr = struct.unpack(weights.HEADER_FMT, blob[:weights.HEADER_BYTES])
-    assert hdr[0] == b"FRPBLOB1" and hdr[1] == 1 and hdr[2] == 128
+    assert hdr[0] == b"FRPBLOB1" and hdr[1] == weights.BLOB_VERSION == 2 and hdr[2] == 128
     n_det, n_det_bufs = hdr[3], hdr[4]
     det_off, emb_off, data_off, data_bytes = hdr[19], hdr[20], hdr[21], hdr[22]
     assert data_off % 256 == 0 and data_off + data_bytes == len(blob)
-    ops = [struct.unpack(weights.OP_FMT, blob[det_off + i * 64: det_off + (i + 1) * 64]) for i in range(n_det)]
+    ob = weights.OP_BYTES
+    ops = [struct.unpack(weights.OP_FMT, blob[det_off + i * ob: det_off + (i + 1) * ob]) for i in range(n_det)]
     layers = netspec.detector_layers((1, 1, 1, 1))
     assert len(ops) == len(layers)
     # replay liveness: a physical buffer may only be overwritten once its previous tensor is dead
