@@ -10,7 +10,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrp.so")
+# FRP_LIB: another build of the same library (same-box A/B of kernel variants: tools/ab_lib.sh)
+LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_HERE, "libfrp.so")
 
 EMB_DIM = 512
 CHIP = 112
