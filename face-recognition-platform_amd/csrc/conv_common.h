@@ -337,15 +337,8 @@ __device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcn
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "add the literal");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 }  // namespace frp
