@@ -2,7 +2,7 @@
 """Per-layer kernel durations and inter-kernel gaps of the LAST pipeline pass in a
 `rocprofv3 --kernel-trace --output-format csv` trace of bench.py (default workload).
 
-    python tools/layer_times.py gpurun_out/kt/kt_kernel_trace.csv
+    python tools/layer_times.py gpurun_out/kt/kt_kernel_trace.csv [frames faces]
 """
 import csv
 import os
@@ -30,7 +30,8 @@ def walk(layers, h0, w0, name, n):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    frames, faces = 32, 320
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    faces = int(sys.argv[3]) if len(sys.argv) > 3 else 10 * frames
     starts = [i for i, r in enumerate(rows) if "stem_u8" in r["Kernel_Name"] or "stem12_u8" in r["Kernel_Name"]]
     seq = rows[starts[-1]:]
     fused2 = "stem12_u8" in seq[0]["Kernel_Name"]
