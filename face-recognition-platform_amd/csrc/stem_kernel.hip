@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
             for (int j = 0; j < 8; ++j) {
                 const int k = 8 * h + j;
                 _Float16 w = (_Float16)0.f;
-                if (k < 9) {
-                    const int kw = k / 3, c = k - kw * 3;
-                    w = p.w1[((co * 3 + kh) * 3 + kw) * 8 + c];
+                if (k < 9) {             // the patch is kept in BGR order (the camera path's memory order: its tiles are
+                    const int kw = k / 3, c = k - kw * 3;   // copied straight); RGB frames are swapped at staging time, so
+                    w = p.w1[((co * 3 + kh) * 3 + kw) * 8 + 2 - c];   // both orders accumulate identically
                 }
                 wa[kh][j] = w;
             }
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
         b1[g] = *reinterpret_cast<const floatx4*>(p.bias1 + 8 * g + 4 * h);
         b2[g] = *reinterpret_cast<const floatx4*>(p.bias2 + 32 * g2 + 8 * g + 4 * h);
     }
-    for (int e = t; e < S12_PATCH_HALFS - S12_PR * S12_PITCH; e += 256) patch[S12_PR * S12_PITCH + e] = (_Float16)0.f;
+    // every halfword of the patch is finite from the start: the windows of the last columns read row tails (and 8
+    // halfwords past the last row) that meet zero weights, and 0 x NaN would not be 0
+    for (int e = t; e < S12_PATCH_HALFS; e += 256) patch[e] = (_Float16)0.f;
 
     // The u8 patch of a tile is fetched as aligned dwords (99 per patch row, 8 per thread) one tile AHEAD:
     // the loads are issued before phase B of the previous tile and unpacked in phase A, so their HBM
@@ -212,6 +214,24 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
     const uint8_t* const buf_lo = p.frames;
     const uint8_t* const buf_hi = p.frames + (long)p.B * p.frame_stride;
     unsigned pre[DW_PER_THREAD];
+    // Interior tiles of BGR frames (84 % at 1080p): the patch is 19 x 393 bytes straight out of the frame.  Thread-invariant part of
+    // the addresses: dword i of this thread is bytes 4d .. 4d+3 of patch row pr - rel[i] bytes from the patch origin in
+    // the frame (one UNALIGNED dword load from a uniform base), ldso[i] bytes into `patch` (one aligned 8-byte write
+    // of 4 halfwords).  Border tiles keep the per-element path (aligned dwords + shift, padding / letterbox logic).
+    int rel[DW_PER_THREAD], ldso[DW_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < DW_PER_THREAD; ++i) {
+        const int idx = t + i * 256;
+        const int pr = idx / DW_ROW, d = idx - pr * DW_ROW;
+        rel[i] = pr < S12_PR ? pr * (int)p.row_stride + 4 * d : -1;
+        ldso[i] = (pr * S12_PITCH + 4 * d) * 2;
+    }
+    bool pre_fast = false;                                      // how `pre` was fetched (uniform)
+    auto tile_interior = [&](int y2_0, int x2_0) {
+        const int iy0 = 4 * y2_0 - 3, ix0 = 4 * x2_0 - 3;
+        // (one pixel of slack on the right: the 99th dword of a row reads 3 bytes past its 393)
+        return iy0 >= 0 && iy0 + S12_PR <= p.H && ix0 >= 0 && ix0 + (2 * S12_S1C + 1) + 1 <= p.W;
+    };
     auto tile_coords = [&](int tile, int& b, int& y2_0, int& x2_0) {
         int q = tile;
         const int tx = q % tiles_x; q /= tiles_x;
@@ -229,6 +249,17 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
     auto prefetch = [&](int tile) {
         int b, y2_0, x2_0;
         tile_coords(tile, b, y2_0, x2_0);
+        pre_fast = !p.rgb_in && tile_interior(y2_0, x2_0);
+        if (pre_fast) {
+            const uint8_t* base = p.frames + (long)b * p.frame_stride + (long)(4 * y2_0 - 3) * p.row_stride + (long)(4 * x2_0 - 3) * 3;
+#pragma unroll
+            for (int i = 0; i < DW_PER_THREAD; ++i) {
+                unsigned v = 0u;
+                if (rel[i] >= 0) __builtin_memcpy(&v, base + (unsigned)rel[i], 4);       // unaligned global_load_dword
+                pre[i] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < DW_PER_THREAD; ++i) {
             const int idx = t + i * 256;
@@ -259,6 +290,23 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
         // ---- A: unpack the prefetched dwords into the normalised fp16 patch (RGB order).  Tiles whose
         // patch lies inside the frame (all but the border ring) skip the per-element padding logic.
         const bool interior = iy0 >= 0 && iy0 + S12_PR <= p.H && ix0 >= 0 && ix0 + (2 * S12_S1C + 1) <= p.W;
+        if (pre_fast) {
+            // u8 -> fp16 without a per-byte convert: bytes b0, b1 dropped into (0x64, b) pairs are the halfwords
+            // 1024 + b; minus 1024, then b * 2^-7 - 255/256 = (b - 127.5) / 128, every step exact in fp16
+            const half2v k1024 = {(_Float16)1024.f, (_Float16)1024.f}, kscale = {(_Float16)0.0078125f, (_Float16)0.0078125f},
+                         kbias = {(_Float16)-0.99609375f, (_Float16)-0.99609375f};
+#pragma unroll
+            for (int i = 0; i < DW_PER_THREAD; ++i) {
+                if (rel[i] >= 0) {
+                    const unsigned lo = __builtin_amdgcn_perm(0x64646464u, pre[i], 0x04010400u);
+                    const unsigned hi = __builtin_amdgcn_perm(0x64646464u, pre[i], 0x04030402u);
+                    const half2v a = __builtin_elementwise_fma(__builtin_bit_cast(half2v, lo) - k1024, kscale, kbias);
+                    const half2v c = __builtin_elementwise_fma(__builtin_bit_cast(half2v, hi) - k1024, kscale, kbias);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(patch) + ldso[i]) =
+                        make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c));
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < DW_PER_THREAD; ++i) {
             const int idx = t + i * 256;
@@ -283,15 +331,18 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
                             // conv padding: 0 in the normalised domain; letterbox canvas: u8 zero
                             v = in_canvas ? (in_frame ? v : (0.f - 127.5f) * (1.0f / 128.0f)) : 0.f;
                         }
-                        prow[px * 3 + (p.rgb_in ? c : 2 - c)] = (_Float16)v;
+                        prow[px * 3 + (p.rgb_in ? 2 - c : c)] = (_Float16)v;
                     }
                     if (++c == 3) { c = 0; ++px; }
                 }
             }
         }
-        for (int e = t; e < S12_PR * (S12_PITCH - S12_PE); e += 256) {   // row tails read by the last windows
+        // row tails read by the last windows (they meet zero weights: any FINITE value will do; the fast path leaves
+        // three normalised bytes of the neighbouring pixel there, this path zeros)
+        for (int e = t; e < S12_PR * (S12_PITCH - S12_PE); e += 256) {
             const int pr = e / (S12_PITCH - S12_PE);
             patch[pr * S12_PITCH + S12_PE + (e - pr * (S12_PITCH - S12_PE))] = (_Float16)0.f;
+        }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < n_tiles) prefetch(tile + gridDim.x);   // lands during phases B and C
