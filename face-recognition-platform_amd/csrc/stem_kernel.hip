@@ -29,6 +29,18 @@ namespace frp {
 #define ST_PE ((2 * ST_COLS + 1) * 3)    // patch elements per row (387)
 #define ST_PITCH 392                     // halfs per patch row
 
+// bias + ReLU + fp16 pack of one accumulator quad, two elements per instruction (v_pk_add_f32, v_cvt_pk_f16_f32,
+// v_pk_max_f16; relu(round16(y)) == round16(relu(y))): -> two dwords of packed halfwords
+__device__ __forceinline__ void bias_relu_pack(const floatx16& acc, int g, floatx4 b, unsigned (&out)[2]) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const float2v v = float2v{acc[4 * g + 2 * h2], acc[4 * g + 2 * h2 + 1]} + float2v{b[2 * h2], b[2 * h2 + 1]};
+        half2v hv = __builtin_convertvector(v, half2v);
+        hv = __builtin_elementwise_max(hv, half2v{0, 0});
+        out[h2] = __builtin_bit_cast(unsigned, hv);
+    }
+}
+
 __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -366,12 +378,13 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
             }
             const int gy = s1r0 + row, gx = s1c0 + col;            // global stem1 coordinates
             const bool inside = (unsigned)gy < (unsigned)p.Ho1 && (unsigned)gx < (unsigned)p.Wo1;
-            union { half4 v; unsigned u[2]; } pk[4];
+            struct { unsigned u[2]; } pk[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    pk[g].v[e] = inside ? (_Float16)fmaxf(acc[4 * g + e] + b1[g][e], 0.f) : (_Float16)0.f;
+            for (int g = 0; g < 4; ++g) {
+                bias_relu_pack(acc, g, b1[g], pk[g].u);
+                pk[g].u[0] = inside ? pk[g].u[0] : 0u;
+                pk[g].u[1] = inside ? pk[g].u[1] : 0u;
+            }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 swap_halves(pk[2 * qq].u[0], pk[2 * qq + 1].u[0]);
@@ -403,11 +416,9 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
                 acc = mfma16(wb[m], *reinterpret_cast<const half8*>(src), acc);
             }
             const int oy = y2_0 + y, ox = x2_0 + r;
-            union { half4 v; unsigned u[2]; } pk[4];
+            struct { unsigned u[2]; } pk[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[g].v[e] = (_Float16)fmaxf(acc[4 * g + e] + b2[g][e], 0.f);
+            for (int g = 0; g < 4; ++g) bias_relu_pack(acc, g, b2[g], pk[g].u);
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 swap_halves(pk[2 * qq].u[0], pk[2 * qq + 1].u[0]);
