@@ -1,0 +1,46 @@
+#!/bin/bash
+# Collects the judged profile set of the CURRENT native sources on the GPU box (run through gpurun):
+#   tools/collect_profiles.sh [outdir under gpurun_out]
+# kernel trace + stats of the bench command, per-layer table, FETCH_SIZE / WRITE_SIZE passes (separate, as the
+# microarchitecture guide prescribes) summarised per kernel family, SQ counters of the stage-3 conv shape.
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/${1:-r2final}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
+    > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+echo "kernel trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 \
+    --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_f.err
+echo "FETCH_SIZE pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 \
+    --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_w.err
+echo "WRITE_SIZE pass done"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES \
+    SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq -o sq -- python3 $R/tools/conv_one.py 320 14 14 256 256 3 1 5 \
+    > /dev/null 2> $O/sq.err
+echo "SQ pass done"
+cd $R
+python tools/layer_times.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/layer_times.txt
+python tools/pmc_summarise.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) 3 \
+    > $O/pmc_traffic.json
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+python - $O <<'PY'
+import csv, sys, glob
+f = glob.glob(sys.argv[1] + "/sq/**/*counter_collection.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+last = max(int(r["Dispatch_Id"]) for r in rows)
+with open(sys.argv[1] + "/conv_lean_stage3_sq_counters.csv", "w") as o:
+    w = csv.DictWriter(o, fieldnames=rows[0].keys())
+    w.writeheader()
+    for r in rows:
+        if int(r["Dispatch_Id"]) == last:
+            w.writerow(r)
+PY
+tail -3 $O/layer_times.txt
+python - $O <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + "/pmc_traffic.json"))
+print("conv traffic GB/step", d["conv_traffic_bytes_per_step"] / 1e9, "hash", d["kernel_source_sha256_16"])
+PY
