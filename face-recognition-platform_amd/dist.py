@@ -69,7 +69,8 @@ def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int
     shard = normalize_rows_f16(make_rows(first, cnt))
     full = allgather_gallery(shard, n_total, device=torch.device("cuda", local_rank))
     torch.cuda.synchronize()
-    engine.gallery_set_device(full.data_ptr(), n_total)
+    for e in (engine if isinstance(engine, (list, tuple)) else [engine]):     # every lane of this GPU gets its own copy
+        e.gallery_set_device(full.data_ptr(), n_total)
     return full.shape[0]
 
 

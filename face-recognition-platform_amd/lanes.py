@@ -1,0 +1,116 @@
+"""Two batches in flight on one GPU.
+
+Every conv launch of the hot path is a persistent kernel of one workgroup per compute unit; its last round of tiles
+leaves CUs idle (490 tiles on 256 CUs), its workgroups finish a few microseconds apart, and the next launch of the
+same stream cannot start before the last of them has.  A second, independent batch on ANOTHER stream fills exactly
+those holes: its workgroups are dispatched onto compute units as the first stream's kernel drains.  Measured on
+MI355X (tools/dual_probe.py, bench.py --lanes 2; 32 x 1080p, 10 faces per frame, IResNet-100): 13.2-13.6 ms per batch
+with two batches in flight against 14.2-14.5 ms with one (+6...8 % faces/s); a third lane gains nothing.
+
+A lane is a complete engine - one C-ABI handle (include/frp.h): private stream, activation buffers, its own copy of
+the weights and of the gallery - so nothing is shared between the batches in flight and every batch gets bit for bit
+the result a single engine would give it.  Each lane is driven by its own host thread (ctypes releases the GIL inside
+the C calls): the hardware scheduler does not serve two queues evenly, and a single thread that waits for the lanes in
+a fixed order leaves the favoured lane idle while it waits for the other one (measured: slower than one lane).
+The caller's loop (reference: one pass per poll, routes/camera.py:225-259) only changes in WHEN it reads a result:
+results are handed back in submission order, at most `n_lanes` batches later.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Dict, Iterable, Iterator, List
+
+import numpy as np
+
+from . import native
+
+
+class Lanes:
+    def __init__(self, device: int = 0, n_lanes: int = 2, **engine_kwargs):
+        if n_lanes < 1:
+            raise ValueError("n_lanes must be >= 1")
+        self.engines: List[native.Engine] = [native.Engine(device, **engine_kwargs) for _ in range(n_lanes)]
+
+    # ---- state that every lane needs a copy of
+    def load_weights(self, blob: bytes) -> None:
+        for e in self.engines:
+            e.load_weights(blob)
+
+    def gallery_set(self, rows: np.ndarray) -> None:
+        for e in self.engines:
+            e.gallery_set(rows)
+
+    def gallery_set_device(self, dev_ptr: int, n: int) -> None:
+        for e in self.engines:
+            e.gallery_set_device(dev_ptr, n)
+
+    def gallery_size(self) -> int:
+        return self.engines[0].gallery_size()
+
+    def close(self) -> None:
+        for e in self.engines:
+            e.close()
+
+    def run(self, batches: Iterable[np.ndarray], max_faces: int = 10, det_thresh: float = 0.5, nms_iou: float = 0.4,
+            flags: int = 0) -> Iterator[Dict[str, np.ndarray]]:
+        """detect + embed + match every batch of host frames [B,H,W,3]; yields the result dicts in submission order.
+        Batch t+1 is pulled from `batches` and runs on another lane while batch t is on the device; at most
+        2 x n_lanes batches are taken ahead of the consumer."""
+        it = iter(batches)
+        n = len(self.engines)
+        cv = threading.Condition()
+        state = {"next": 0, "done": {}, "exhausted": False, "error": None, "yielded": 0}
+
+        def worker(e: native.Engine) -> None:
+            while True:
+                with cv:
+                    while state["next"] - state["yielded"] >= 2 * n and state["error"] is None:
+                        cv.wait()
+                    if state["exhausted"] or state["error"] is not None:
+                        return
+                    try:
+                        frames = next(it)
+                    except StopIteration:
+                        state["exhausted"] = True
+                        cv.notify_all()
+                        return
+                    except BaseException as ex:      # the caller's iterator failed: surface it in run()
+                        state["error"] = ex
+                        cv.notify_all()
+                        return
+                    t = state["next"]
+                    state["next"] += 1
+                try:
+                    out = e.process_frames(frames, max_faces=max_faces, det_thresh=det_thresh, nms_iou=nms_iou, flags=flags)
+                except BaseException as ex:
+                    with cv:
+                        state["error"] = ex
+                        cv.notify_all()
+                    return
+                with cv:
+                    state["done"][t] = out
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
+        for th in threads:
+            th.start()
+        try:
+            while True:
+                with cv:
+                    while (state["yielded"] not in state["done"] and state["error"] is None
+                           and not (state["exhausted"] and state["yielded"] >= state["next"])):
+                        cv.wait()
+                    if state["error"] is not None:
+                        raise state["error"]
+                    if state["yielded"] not in state["done"]:
+                        return
+                    out = state["done"].pop(state["yielded"])
+                    state["yielded"] += 1
+                    cv.notify_all()
+                yield out
+        finally:
+            with cv:
+                state["exhausted"] = True       # consumer gone (or done): workers stop after their current batch
+                cv.notify_all()
+            for th in threads:
+                th.join()

@@ -100,6 +100,44 @@ def test_forced_k_and_resident_path(engine):
     assert np.array_equal(a["emb"], d["emb"])
 
 
+def test_two_batches_in_flight_equal_one_at_a_time(engine):
+    """lanes.Lanes (two handles = two streams, one host thread each; batch t+1 runs while batch t is on the device):
+    every batch gets bit for bit the result of a plain call on a single engine, in submission order, also with ragged
+    batch shapes and in threshold mode; an error in the caller's iterator or in a lane surfaces in the consumer"""
+    from frp_amd.lanes import Lanes
+    rng = np.random.default_rng(909)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    G = rng.standard_normal((700, 512)).astype(np.float32)
+    engine.gallery_set(G)
+    lanes = Lanes(0, 2, max_batch=4, max_faces=4, max_h=160, max_w=192)
+    lanes.load_weights(blob)
+    lanes.gallery_set(G)
+    shapes = [(3, 128, 160), (4, 160, 192), (1, 96, 128), (3, 128, 160), (2, 160, 192), (4, 128, 160), (1, 160, 192)]
+    batches = [_frames(rng, *s_) for s_ in shapes]
+    for flags, thr in ((1, 0.5), (0, 0.3)):
+        want = [engine.process_frames(f, max_faces=4, det_thresh=thr, flags=flags) for f in batches]
+        got = list(lanes.run(batches, max_faces=4, det_thresh=thr, flags=flags))
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            for key in ("counts", "boxes", "kps", "scores", "emb", "match_idx", "match_cos"):
+                assert np.array_equal(g[key], w_[key]), key
+    assert list(lanes.run([], max_faces=4)) == []
+
+    def broken():
+        yield batches[0]
+        raise KeyError("camera gone")
+    with pytest.raises(KeyError):
+        list(lanes.run(broken(), max_faces=4, flags=1))
+    with pytest.raises(ValueError):                                 # a lane's own failure (bad frame shape)
+        list(lanes.run([batches[0], np.zeros((1, 8, 8, 4), np.uint8)], max_faces=4, flags=1))
+    # an abandoned generator stops its workers
+    gen = lanes.run(batches, max_faces=4, flags=1)
+    next(gen)
+    gen.close()
+    lanes.close()
+
+
 def test_overlapped_ingest_equals_plain_calls(engine):
     """upload_async(t+1) | process(t) | fetch(t) | swap: every batch gives exactly the results of a plain
     process_frames call, also when the batch shape changes and when the staged copy is still running
