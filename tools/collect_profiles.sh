@@ -11,16 +11,17 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
     > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 echo "kernel trace done"
-# the same command without the side loops: every pass in this trace is a forced-K pass of the timed-region kind, so the
-# per-kernel averages are comparable with the bench line's and the LAST pass is what tools/layer_times.py labels
+# one batch at a time, no side loops: every pass in this trace is a forced-K pass whose kernels own the chip, so the
+# per-kernel averages are the ones `roofline` is computed from (in the default command two batches are in flight and
+# kernel durations of the two streams overlap) and the LAST pass is what tools/layer_times.py labels
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_timed -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
-    --pcie-steps 0 --threshold-steps 0 > $O/bench_under_rocprof_timed_region_only.json 2> $O/bench_under_rocprof_timed.err
+    --lanes 1 --pcie-steps 0 --threshold-steps 0 > $O/bench_under_rocprof_one_batch_at_a_time.json 2> $O/bench_under_rocprof_timed.err
 echo "kernel trace (timed region only) done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 \
-    --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_f.err
+    --lanes 1 --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_f.err
 echo "FETCH_SIZE pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 \
-    --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_w.err
+    --lanes 1 --pcie-steps 0 --threshold-steps 0 > /dev/null 2> $O/pmc_w.err
 echo "WRITE_SIZE pass done"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq -o sq -- python3 $R/tools/conv_one.py 320 14 14 256 256 3 1 5 \
@@ -31,7 +32,7 @@ python tools/layer_times.py $(find $O/kt_timed -name "*kernel_trace.csv" | head 
 python tools/pmc_summarise.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) 3 \
     > $O/pmc_traffic.json
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-cp $(find $O/kt_timed -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats_timed_region_only.csv
+cp $(find $O/kt_timed -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats_one_batch_at_a_time.csv
 python - $O <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/sq/**/*counter_collection.csv", recursive=True)[0]
