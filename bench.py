@@ -14,6 +14,9 @@ import time
 
 import numpy as np
 
+# two lanes per GPU next to torch + RCCL need more than the default 4 hardware queues (see native.py); before any HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -10,6 +10,13 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Two handles that keep two batches
+# in flight on one GPU (lanes.py) need their compute streams on DIFFERENT queues; next to torch's and RCCL's streams four
+# queues were not enough (measured: no gain from the second lane in 3 of 3 processes with 4 queues, the full gain in 5 of
+# 5 with 8).  The runtime reads the variable when it initialises, so this only helps when this module is imported before
+# the first HIP call of the process - export it in the service's environment otherwise.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # FRP_LIB: another build of the same library (same-box A/B of kernel variants: tools/ab_lib.sh)
 LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_HERE, "libfrp.so")
 
