@@ -376,3 +376,67 @@ def test_fp8_weight_codec_and_blob():
         assert op[8] & wts.OPFLAG_W_FP8
     with pytest.raises(ValueError):
         wts.pack_blob(raw, (1, 1, 1, 1), (1, 1, 1, 1), weight_format="int4")
+
+
+def test_lanes_keep_submission_order_and_surface_errors(monkeypatch):
+    """lanes.Lanes host logic without a GPU: batches are spread over the lanes' threads, results come back in submission
+    order even when a later batch finishes first, the look-ahead is bounded, errors of the iterator and of a lane reach
+    the consumer, an abandoned generator stops its workers"""
+    import threading
+    import time
+    from frp_amd import lanes as lanes_mod
+
+    class SlowEngine:
+        made = []
+
+        def __init__(self, device, **kw):
+            self.calls = []
+            self.closed = False
+            SlowEngine.made.append(self)
+
+        def process_frames(self, frames, **kw):
+            t = int(frames[0])
+            if t < 0:
+                raise RuntimeError("lane failure")
+            time.sleep(0.03 if t % 2 == 0 else 0.001)       # even batches are slow: odd ones overtake them
+            self.calls.append((t, threading.get_ident()))
+            return {"t": t, "kw": kw}
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(lanes_mod.native, "Engine", SlowEngine)
+    L = lanes_mod.Lanes(0, 2, max_batch=4)
+    assert len(SlowEngine.made) == 2
+    pulled = []
+
+    def src(n):
+        for t in range(n):
+            pulled.append(t)
+            yield np.array([t])
+    got = []
+    for out in L.run(src(12), max_faces=3, flags=1):
+        got.append(out["t"])
+        assert len(pulled) - len(got) <= 2 * 2             # at most 2 x n_lanes batches taken ahead of the consumer
+        assert out["kw"]["max_faces"] == 3 and out["kw"]["flags"] == 1
+    assert got == list(range(12))
+    assert all(e.calls for e in SlowEngine.made)            # both lanes worked, each on its own thread
+    assert len({tid for e in SlowEngine.made for _, tid in e.calls}) == 2
+    assert list(L.run(iter(()))) == []
+
+    def bad_iter():
+        yield np.array([0])
+        raise KeyError("camera gone")
+    with pytest.raises(KeyError):
+        list(L.run(bad_iter()))
+    with pytest.raises(RuntimeError):
+        list(L.run([np.array([0]), np.array([-1]), np.array([2])]))
+    before = threading.active_count()
+    g = L.run(src(50))
+    next(g)
+    g.close()
+    assert threading.active_count() <= before
+    L.close()
+    assert all(e.closed for e in SlowEngine.made)
+    with pytest.raises(ValueError):
+        lanes_mod.Lanes(0, 0)

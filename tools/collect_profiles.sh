@@ -27,6 +27,10 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
     SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq -o sq -- python3 $R/tools/conv_one.py 320 14 14 256 256 3 1 5 \
     > /dev/null 2> $O/sq.err
 echo "SQ pass done"
+# the multi-GPU process shape on this one-GPU box: torch + RCCL initialised, gallery all-gather, two lanes
+(cd $R && FRP_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 1 --steps 10 --warmup 2 --cpu-frames 0 > $O/bench_dist_rehearsal_1rank.json 2> $O/bench_dist_rehearsal.err) || true
+echo "RCCL rehearsal done"
 cd $R
 python tools/layer_times.py $(find $O/kt_timed -name "*kernel_trace.csv" | head -1) > $O/layer_times.txt
 python tools/pmc_summarise.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) 3 \
