@@ -334,6 +334,48 @@ def main():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # The same with HOST frames every step (never `value`): each lane's thread uploads its batch from page-locked memory
+    # on its own stream (the copy runs under the other lane's kernels), processes it and fetches the results.
+    h2h_lanes = None
+    if L > 1 and args.pcie_steps != 0 and rank == 0:
+        n_h = args.steps if args.pcie_steps < 0 else args.pcie_steps
+        pinned = [[e_.host_frames(B, H, W) for _ in range(2)] for e_ in lanes]
+        for pp_ in pinned:
+            for p_ in pp_:
+                p_[...] = frames
+        for i_, e_ in enumerate(lanes):              # prime each lane's overlapped-ingest loop (as in the one-lane side line)
+            e_.upload_frames_async(pinned[i_][0])
+            e_.swap_frames()
+            e_.upload_frames_async(pinned[i_][1])
+
+        def lane_loop_h2h(i, counter):
+            j = 0
+            while True:
+                with counter["lock"]:
+                    if counter["next"] >= n_h:
+                        return
+                    counter["next"] += 1
+                lanes[i].process_resident(K, flags=flags)
+                last[i] = lanes[i].fetch_results()
+                lanes[i].swap_frames()                               # the batch uploaded during this step becomes resident
+                lanes[i].upload_frames_async(pinned[i][j & 1])       # next batch: copy stream, under both lanes' kernels
+                j += 1
+
+        for e_ in lanes:
+            e_.synchronize()
+        counter = {"next": 0, "lock": threading.Lock()}
+        th = [threading.Thread(target=lane_loop_h2h, args=(i, counter)) for i in range(L)]
+        t_h = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for e_ in lanes:
+            e_.synchronize()
+        dt_h = time.perf_counter() - t_h
+        h2h_lanes = {"faces_per_s": round(n_h * B * K / dt_h, 1), "ms_per_step": round(dt_h / n_h * 1e3, 3), "steps": n_h,
+                     "mode": f"{L} lanes, each running the overlapped-ingest loop (page-locked host frames, H2D on the lane's copy "
+                             "stream under the kernels of both lanes, host results out every step)"}
     done_ = [r_ for r_ in last if r_ is not None]
     assert done_ and all(np.all(r_["counts"] == K) for r_ in done_)
     res = done_[0]
@@ -430,7 +472,7 @@ def main():
                        "frames_per_s": round(world * args.steps * B / dt, 2),
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
                        "lanes": L, "one_batch_at_a_time": single,
-                       "host_to_host": pcie,
+                       "host_to_host": pcie, "host_to_host_lanes": h2h_lanes,
                        "threshold_mode": thr,
                        "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
                        "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),
