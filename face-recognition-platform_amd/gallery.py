@@ -16,12 +16,101 @@ from typing import Dict, Iterator, List, Optional
 import numpy as np
 
 
+class _RWLock:
+    """Writers (gallery updates, and every reader that takes `Gallery.locked()`) are exclusive and re-entrant per thread;
+    shared readers (`Gallery.reading()`: the streaming lanes, which resolve device rows to names for several batches at
+    once) run together.  Waiting writers hold back new readers."""
+
+    def __init__(self):
+        self._cv = threading.Condition(threading.Lock())
+        self._readers = 0
+        self._writer: Optional[int] = None
+        self._depth = 0
+        self._waiting_writers = 0
+
+    # exclusive side: usable as `with lock:`
+    def acquire(self):
+        me = threading.get_ident()
+        with self._cv:
+            if self._writer == me:
+                self._depth += 1
+                return True
+            self._waiting_writers += 1
+            while self._readers > 0 or self._writer is not None:
+                self._cv.wait()
+            self._waiting_writers -= 1
+            self._writer, self._depth = me, 1
+            return True
+
+    def release(self):
+        with self._cv:
+            self._depth -= 1
+            if self._depth == 0:
+                self._writer = None
+                self._cv.notify_all()
+
+    __enter__ = acquire
+
+    def __exit__(self, *exc):
+        self.release()
+
+    # shared side
+    def acquire_read(self):
+        me = threading.get_ident()
+        with self._cv:
+            if self._writer == me:              # a reader inside its own exclusive section
+                self._depth += 1
+                return
+            while self._writer is not None or self._waiting_writers > 0:
+                self._cv.wait()
+            self._readers += 1
+
+    def release_read(self):
+        me = threading.get_ident()
+        with self._cv:
+            if self._writer == me:
+                self._depth -= 1
+                return
+            self._readers -= 1
+            if self._readers == 0:
+                self._cv.notify_all()
+
+
+class _Reading:
+    def __init__(self, lock: _RWLock):
+        self._l = lock
+
+    def __enter__(self):
+        self._l.acquire_read()
+
+    def __exit__(self, *exc):
+        self._l.release_read()
+
+
 class Gallery(Mapping):
     def __init__(self, engine_getter):
         self._eng = engine_getter          # callable -> native.Engine (created lazily)
+        self._mirrors: List = []           # further engines holding a copy of the matrix (the second lane of a GPU)
         self._rows: Dict[str, int] = {}    # insertion-ordered: name -> device row
         self._names: List[Optional[str]] = []   # device row -> name
-        self._lock = threading.RLock()
+        self._lock = _RWLock()
+
+    def add_mirror(self, engine) -> None:
+        """A second engine that receives every update from now on (two batches in flight on one GPU: each lane matches
+        against its own copy).  Only while the gallery is empty: both copies are then built from the same fp32 rows by
+        the same kernel and stay bit-identical."""
+        with self._lock:
+            if self._names:
+                raise ValueError("mirrors must be added before the gallery is filled")
+            self._mirrors.append(engine)
+
+    def _engines(self):
+        return [self._eng()] + list(self._mirrors)
+
+    def reading(self):
+        """Shared access for a reader that resolves device rows to names: like `locked()` it keeps updates out between
+        its device call and its lookup, but several such readers (the lanes of a GPU) may be inside together."""
+        return _Reading(self._lock)
 
     # ---- Mapping view (values are fetched from the device on demand)
     def __len__(self) -> int:
@@ -63,10 +152,12 @@ class Gallery(Mapping):
         with self._lock:
             e = np.asarray(emb, dtype=np.float32).reshape(-1)
             if name in self._rows:
-                self._eng().gallery_update_row(self._rows[name], e)
+                for eng in self._engines():
+                    eng.gallery_update_row(self._rows[name], e)
                 return True
             row = len(self._names)
-            self._eng().gallery_update_row(row, e)     # row == size appends
+            for eng in self._engines():
+                eng.gallery_update_row(row, e)         # row == size appends
             self._rows[name] = row
             self._names.append(name)
             return False
@@ -77,7 +168,8 @@ class Gallery(Mapping):
                 return False
             row = self._rows.pop(name)
             last = len(self._names) - 1
-            self._eng().gallery_remove_row(row)        # device: last row moves into `row`
+            for eng in self._engines():
+                eng.gallery_remove_row(row)            # device: last row moves into `row`
             if row != last:
                 moved = self._names[last]
                 self._names[row] = moved
@@ -90,20 +182,22 @@ class Gallery(Mapping):
         with self._lock:
             if len(set(names)) != len(names) or len(names) != len(emb):
                 raise ValueError("names must be unique and match the rows")
-            self._eng().gallery_set(np.asarray(emb))
+            for eng in self._engines():
+                eng.gallery_set(np.asarray(emb))
             self._rows = {n: i for i, n in enumerate(names)}
             self._names = list(names)
 
     def adopt_device(self, names: List[str]):
         """name table for a matrix that was installed with frp_gallery_set_device."""
         with self._lock:
-            if self._eng().gallery_size() != len(names):
+            if any(eng.gallery_size() != len(names) for eng in self._engines()):
                 raise ValueError("name table does not match the device gallery")
             self._rows = {n: i for i, n in enumerate(names)}
             self._names = list(names)
 
     def clear(self):
         with self._lock:
-            self._eng().gallery_set(np.zeros((0, 512), np.float32))
+            for eng in self._engines():
+                eng.gallery_set(np.zeros((0, 512), np.float32))
             self._rows.clear()
             self._names.clear()

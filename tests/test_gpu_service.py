@@ -279,3 +279,68 @@ def test_staged_ingest_of_encoded_stills(engine, tmp_path):
     with pytest.raises(ValueError):
         ing.decode_into(0, [np.zeros((10, 10, 3), np.uint8)])
     engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_process_stream_two_lanes_on_device(engine):
+    """FaceService.process_stream: two real handles (two batches in flight), enrolled faces are recognised in every
+    batch exactly as process_frames recognises them (same boxes, embeddings, targets, distances: bit for bit), in
+    submission order; identities enrolled and deleted WHILE the stream runs reach both gallery copies and never
+    mis-attribute a face"""
+    import threading
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    fs = FaceService(weights_blob=blob)
+    assert fs.enable_second_lane()                      # before the gallery is filled
+    rng = np.random.default_rng(31)
+    batches = [rng.integers(0, 256, size=(b_, 96, 128, 3), dtype=np.uint8) for b_ in (2, 3, 1, 2, 3, 2, 1, 3)]
+    # enrol the first face of every frame of the first two batches
+    seen = fs.process_frames(np.concatenate(batches[:2]), max_faces=2, det_thresh=0.0)
+    k = 0
+    for faces in seen:
+        if faces:
+            assert fs.store_face(f"p{k}", faces[0]["embedding"])["success"]
+            k += 1
+    assert k >= 3
+    want = [fs.process_frames(f, max_faces=2, det_thresh=0.0) for f in batches]
+    got = list(fs.process_stream(batches, max_faces=2, det_thresh=0.0))
+    assert len(got) == len(want)
+    n_named = 0
+    for g, w_ in zip(got, want):
+        assert len(g) == len(w_)
+        for fg, fw in zip(g, w_):
+            assert len(fg) == len(fw)
+            for a, b in zip(fg, fw):
+                assert a["bbox"] == b["bbox"] and a["target"] == b["target"] and a["distance"] == b["distance"]
+                assert np.array_equal(a["embedding"], b["embedding"])
+                n_named += a["target"] is not None and a["match"]
+    assert n_named >= 3
+    # churn while streaming
+    E = rng.standard_normal((30, 512)).astype(np.float32)
+    stop = threading.Event()
+    errs = []
+
+    def churn():
+        try:
+            j = 0
+            while not stop.is_set():
+                assert fs.store_face(f"tmp{j % 10}", E[j % 30])["success"]
+                if j >= 3:
+                    fs.delete_face(f"tmp{(j - 3) % 10}")
+                j += 1
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        for rep in range(3):
+            for g, w_ in zip(fs.process_stream(batches, max_faces=2, det_thresh=0.0), want):
+                for fg, fw in zip(g, w_):
+                    for a, b in zip(fg, fw):
+                        if b["match"]:                       # an enrolled face keeps its identity whatever comes and goes
+                            assert a["target"] == b["target"] and abs(a["distance"] - b["distance"]) < 1e-6
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+    e1, e2 = fs._eng(), fs._eng2()
+    assert e1.gallery_size() == e2.gallery_size() == len(fs.ENCODINGS)
+    assert np.array_equal(e1.gallery_get(), e2.gallery_get())

@@ -440,3 +440,105 @@ def test_lanes_keep_submission_order_and_surface_errors(monkeypatch):
     assert all(e.closed for e in SlowEngine.made)
     with pytest.raises(ValueError):
         lanes_mod.Lanes(0, 0)
+
+
+def test_gallery_rw_lock_and_mirrors():
+    """Gallery host logic for two lanes: updates reach every mirror, mirrors only join an empty gallery, shared readers
+    run together while a writer waits for them and keeps later readers out"""
+    import threading
+    import time
+    from frp_amd.gallery import Gallery
+    a, b = FakeEngine(), FakeEngine()
+    G = Gallery(lambda: a)
+    G.add_mirror(b)
+    rng = np.random.default_rng(3)
+    E = rng.standard_normal((5, 512)).astype(np.float32)
+    for i in range(4):
+        G.put(f"p{i}", E[i])
+    G.remove("p1")                                   # swap-remove on both copies
+    G.put("p0", E[4])                                # overwrite on both copies
+    assert np.array_equal(a.G, b.G) and len(a.G) == 3 and G.names() == ["p0", "p2", "p3"]
+    G.set_bulk(["x", "y"], E[:2])
+    assert np.array_equal(a.G, b.G) and len(b.G) == 2
+    with pytest.raises(ValueError):
+        G.add_mirror(FakeEngine())                   # not into a filled gallery
+    G.clear()
+    assert len(a.G) == len(b.G) == 0
+
+    log = []
+    inside = threading.Barrier(2, timeout=5)
+
+    def reader(tag):
+        with G.reading():
+            inside.wait()                            # both readers are inside together
+            log.append(("r-in", tag))
+            time.sleep(0.05)
+            log.append(("r-out", tag))
+
+    def writer():
+        with G.locked():
+            with G.locked():                         # re-entrant
+                with G.reading():                    # and may read inside its own exclusive section
+                    log.append(("w", 0))
+    r = [threading.Thread(target=reader, args=(i,)) for i in range(2)]
+    for t in r:
+        t.start()
+    time.sleep(0.01)
+    w = threading.Thread(target=writer)
+    w.start()
+    time.sleep(0.01)
+    late = threading.Thread(target=lambda: (G.reading().__enter__(), log.append(("late", 0)), G._lock.release_read()))
+    late.start()
+    for t in r + [w, late]:
+        t.join(timeout=5)
+        assert not t.is_alive()
+    order = [e[0] for e in log]
+    assert order.index("w") > max(i for i, e in enumerate(order) if e == "r-out")      # the writer waited for both readers
+    assert order.index("late") > order.index("w")                                      # and went before the late reader
+
+
+def test_process_stream_two_lanes_host_logic():
+    """FaceService.process_stream with two (fake) engines: results in submission order, equal to process_frames batch by
+    batch, both engines used, enrolment during the stream reaches both gallery copies"""
+    import time
+    a, b = FakeEngine(), FakeEngine()
+    svc = FaceService(engine=a, second_engine=b)
+    rng = np.random.default_rng(11)
+    E = rng.standard_normal((6, 512)).astype(np.float32)
+    for i in range(4):
+        assert svc.store_face(f"id{i}", E[i].tolist())["success"]
+    assert np.array_equal(a.G, b.G)
+    used = []
+
+    def canned_for(eng, tag):
+        def pf(frames, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
+            t = int(frames[0, 0, 0, 0])
+            used.append(tag)
+            time.sleep(0.02 if t % 2 == 0 else 0.001)
+            q = E[t % 4][None]
+            idx, cos = eng.match(q)
+            return {"counts": np.array([1]), "boxes": np.zeros((1, 1, 4), np.float32) + t, "kps": np.zeros((1, 1, 10), np.float32),
+                    "scores": np.ones((1, 1), np.float32), "emb": q[None].astype(np.float32),
+                    "match_idx": np.array([[idx[0]]], np.int32), "match_cos": np.array([[cos[0]]], np.float32)}
+        return pf
+    a.process_frames = canned_for(a, "a")
+    b.process_frames = canned_for(b, "b")
+    batches = [np.full((1, 4, 4, 3), t, np.uint8) for t in range(10)]
+    got = list(svc.process_stream(batches, max_faces=1))
+    assert [g[0][0]["bbox"][0] for g in got] == list(range(10))                      # submission order
+    assert [g[0][0]["target"] for g in got] == [f"id{t % 4}" for t in range(10)]
+    assert set(used) == {"a", "b"}
+    want = [svc.process_frames(f, max_faces=1) for f in batches]
+    for g, w_ in zip(got, want):
+        assert g[0][0]["target"] == w_[0][0]["target"] and g[0][0]["distance"] == w_[0][0]["distance"]
+    # enrol while a stream is running: both copies get the row, later batches can match it
+    gen = svc.process_stream(batches, max_faces=1)
+    next(gen)
+    assert svc.store_face("late", E[5].tolist())["success"]
+    list(gen)
+    assert np.array_equal(a.G, b.G) and len(a.G) == 5
+    # a service whose gallery was filled before the second lane could join streams on one lane
+    solo = FaceService(engine=FakeEngine())
+    solo._eng().process_frames = canned_for(solo._eng(), "solo")
+    assert solo.store_face("id0", E[0].tolist())["success"]
+    assert len(list(solo.process_stream(batches[:3], max_faces=1))) == 3
