@@ -23,7 +23,14 @@ def walk(layers, h0, w0, name, n):
         oh, ow = (1, 1) if flat else ns.out_hw(h, w, l.k, l.stride)
         dims[l.dst] = (oh, ow)
         fl = 2 * n * oh * ow * (l.cout_real or l.cout) * (l.cin_real or l.cin) * (1 if flat else l.k * l.k)
-        out.append((l, h, w, fl))
+        # algorithmic HBM bytes: the input pixels a stride-s kernel touches (every pixel for 3x3, every s-th row and column
+        # for 1x1), the output, the residual, the weights; fp16 unless the output is fp32
+        touched = n * h * w if (l.k > 1 or flat) else n * oh * ow
+        by = touched * l.cin * 2 + n * oh * ow * l.cout * (4 if (l.flags & ns.FLAG_OUT_F32) else 2) + l.cout * l.cin * (1 if flat else l.k * l.k) * 2
+        if l.res:
+            rh, rw = dims[l.res]
+            by += n * rh * rw * l.cout * 2
+        out.append((l, h, w, fl, by))
     return out
 
 
@@ -40,6 +47,7 @@ def main():
     emb_stem = any("emb_stem" in r["Kernel_Name"] for r in seq)      # the embedder's first conv runs in its own kernel
     convs = iter(det[2 if fused2 else 1:] + emb[1 if emb_stem else 0:])
     prev_end, t0, tot, tot_gap = None, int(seq[0]["Start_Timestamp"]), 0.0, 0.0
+    bounds = []
     for r in seq:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - prev_end) / 1e3 if prev_end else 0.0
@@ -49,13 +57,22 @@ def main():
         tot_gap += gap
         name = r["Kernel_Name"]
         if "conv_mfma" in name or "conv3x3_rows" in name or "conv3x3_lean" in name:
-            l, h, w, fl = next(convs)
+            l, h, w, fl, by = next(convs)
             cfg = re.search(r"<(\d+), (\d+),", name)
+            # what this launch cannot beat on this device: its FLOPs at the k-loop's own rate (1.25 PFLOP/s)
+            # or its algorithmic bytes at 4.5 TB/s (the best streaming rate measured here), whichever is longer
+            bound = max(fl / 1.25e9, by / 4.5e6)
+            bounds.append((d, bound))
             print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
-                  f"{d:8.1f} us  gap {gap:6.1f}  {fl / d / 1e6:7.1f} TF  tile {cfg.group(1)}x{cfg.group(2)}")
+                  f"{d:8.1f} us  gap {gap:6.1f}  {fl / d / 1e6:7.1f} TF  {by / d / 1e3:7.1f} GB/s  x{d / bound:4.2f} of "
+                  f"{'mfma' if fl / 1.25e9 >= by / 4.5e6 else 'hbm '} bound  tile {cfg.group(1)}x{cfg.group(2)}")
         else:
             print(f"{name[:57]:57s} grid {r['Grid_Size_X']:>9s} {d:8.1f} us  gap {gap:6.1f}")
     print(f"sum of kernels {tot:.1f} us, sum of gaps {tot_gap:.1f} us, span {(prev_end - t0) / 1e3:.1f} us")
+    if bounds:
+        td, tb = sum(d for d, _ in bounds), sum(b for _, b in bounds)
+        print(f"conv launches: {td:.1f} us against {tb:.1f} us of per-launch bounds (max of FLOPs at 1.25 PFLOP/s, algorithmic bytes "
+              f"at 4.5 TB/s): x{td / tb:.2f}")
 
 
 if __name__ == "__main__":
