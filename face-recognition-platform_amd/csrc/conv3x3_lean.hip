@@ -36,19 +36,27 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
 // (tools/kstep_lab.py: 3.16 vs 1.27 PFLOP/s for the k-step with barrier and DMA).  Per-cout weight scales (and the input
 // tensor's scale) multiply the fp32 accumulator in the epilogue; outputs leave as fp16, as fp8, or as both.
 typedef int intx8 __attribute__((ext_vector_type(8)));
-template <int TC, int WP, int WC, bool F8>
+//
+// TP = 512 (Cout <= 64): at 256 pixels a 64-cout tile leaves each wave a 32 x 64 tile - 1.5 fragment reads per MFMA, and
+// the LDS read port, not the matrix pipe, sets the pace.  512 pixels x 64 couts gives every wave the 64 x 64 tile of the
+// 128-cout configuration (1.0 reads per MFMA).  Two 65 KiB patches are all the LDS holds then, so the patch ring has
+// TWO slots: a row's patch is fired ONE row ahead (during the first two k-steps of the row before it: 9 pieces per wave,
+// 5 + 4), its slot is the running patch parity (a scalar, not a constant), and the counted waits change accordingly.
+template <int TC, int WP, int WC, bool F8, int TP>
 __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    constexpr int TP = 256, NW = 8;
-    constexpr int XROWS = 264;                // 33 groups of 8 rows; rows 0..257 are read
-    constexpr int XSLOT = XROWS * 128;        // 33,792 B (a multiple of 256)
+    constexpr int NW = 8;
+    constexpr int NXS = TP == 256 ? 3 : 2;    // patch ring slots
+    constexpr int NQ = TP / 64;               // row groups (of 8 rows) per wave; one more group is shared
+    constexpr int XROWS = TP + 8;             // TP/8 + 1 groups of 8 rows; rows 0..TP+1 are read
+    constexpr int XSLOT = XROWS * 128;        // 33,792 / 66,560 B (multiples of 256)
     constexpr int WSLOT = TC * 128;
     constexpr int WI = TC / 8 / NW;           // weight DMA pieces per wave per k-step (2 or 1)
     constexpr int MP = TP / WP / 32, MC = TC / WC / 32;
-    constexpr int OFF_W = 3 * XSLOT;
+    constexpr int OFF_W = NXS * XSLOT;
     constexpr int OFF_Z = OFF_W + 3 * WSLOT;  // 256 zero bytes (256-aligned)
     constexpr int OFF_PAR = OFF_Z + 256;
-    static_assert(WP * WC == NW && (WI == 1 || WI == 2) && MP * MC <= 4 && (OFF_Z & 255) == 0, "layout");
+    static_assert(WP * WC == NW && (WI == 1 || WI == 2) && MP * MC <= 4 && (OFF_Z & 255) == 0 && (TP == 256 || (TP == 512 && WI == 1 && !F8)), "layout");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -97,18 +105,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         const int pt = tile / p.n_ctiles;
         const int m0i = pt * TP, c0i = (tile - pt * p.n_ctiles) * TC;
         d.xg = (m0i - p.W - 1 + wave * 8 + lrow) * cin2 + lchunk * 16;
-        d.xg32 = (m0i - p.W - 1 + 256 + lrow) * cin2 + lchunk32 * 16;
+        d.xg32 = (m0i - p.W - 1 + TP + lrow) * cin2 + lchunk32 * 16;
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int co = c0i + (i * NW + wave) * 8 + lrow;
             d.woff[i] = co < p.Cout ? (unsigned)(co * p.Ktot * ES + lchunk * 16) : CONV_OOB;
         }
     };
-    // piece q (0..3: row group wave + 8q, 4: group 32) of patch (cb byte offset cbs, kernel row kh) into ring slot `slot`
+    // piece q (0..NQ-1: row group wave + 8q, NQ: the last group, TP/8) of patch (cb byte offset cbs, kernel row kh) into
+    // ring slot `slot`
     auto x_piece = [&](const Desc& d, int q, int kh, int cbs, int slot) {
         const int rs = kh * khpitch + cbs;
-        if (q < 4) dma16(xrsrc, smem + slot * XSLOT + (wave + 8 * q) * 1024, (unsigned)(d.xg + rs + q * 64 * cin2));
-        else dma16(xrsrc, smem + slot * XSLOT + 32 * 1024, (unsigned)(d.xg32 + rs));
+        if (q < NQ) dma16(xrsrc, smem + slot * XSLOT + (wave + 8 * q) * 1024, (unsigned)(d.xg + rs + q * 64 * cin2));
+        else dma16(xrsrc, smem + slot * XSLOT + (TP / 8) * 1024, (unsigned)(d.xg32 + rs));
     };
     // weight stage (tap, cb byte offset cbs) into ring slot `slot`: this wave's WI pieces
     auto w_stage = [&](const Desc& d, int tap, int cbs, int slot) {
@@ -225,12 +234,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     __syncthreads();
     Desc cur, nt;
     make_desc(t0, cur);
+    if constexpr (NXS == 3) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) x_piece(cur, q, r, 0, r);
-        w_stage(cur, r, 0, r);
+            for (int q = 0; q < 5; ++q) x_piece(cur, q, r, 0, r);
+            w_stage(cur, r, 0, r);
+        }
+    } else {                                   // two slots: row 0 now, row 1 during row 0's k-steps
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) x_piece(cur, q, 0, 0, 0);
+        w_stage(cur, 0, 0, 0);
+        w_stage(cur, 1, 0, 1);
     }
+    int xs = 0;                                // NXS == 2: byte offset of the patch slot the running row reads
     const bool has_res = p.res != nullptr;
 
     // ---------------- epilogue of a tile (as conv3x3_rows.hip): bias / border-class bias from the LDS parameter cache,
@@ -319,6 +336,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
         if (TAP == 0 && cb == 0) store_params();                                                                \
     } while (0)
 
+        // Two-slot schedule (TP = 512).  Row KH reads slot xs and fires the NEXT row's patch (row KH + 1 of this channel
+        // block, or row 0 of what lies beyond it) into the other slot: 5 pieces in its first k-step, 4 in its second.
+        // In-flight budget at the barrier of a step (vmcnt retires in issue order; a step issues its weight stage first):
+        //   kw = 0 needs the patch, last fired in the previous kw = 1 step - behind it only the kw = 2 weight stage: 1
+        //   kw = 1 needs weight stage TAP, fired in the previous kw = 2 step - behind it this row's kw = 0 issue: 1 + 5
+        //   kw = 2 needs weight stage TAP, first issue of this row's kw = 0 step - behind it 5 + (1 + 4): 10
+#define LEAN2_STEP(KH, KW)                                                                                      \
+    do {                                                                                                        \
+        constexpr int TAP = (KH) * 3 + (KW);                                                                    \
+        if (TAP == 0 && cb == 0) wait_vmcnt<0>();                                                               \
+        else if ((KW) == 0) wait_vmcnt<1>();                                                                    \
+        else if ((KW) == 1) wait_vmcnt<6>();                                                                    \
+        else wait_vmcnt<10>();                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                          \
+            bbase[i] = ((tapmask[i] >> TAP) & 1u) ? xs + pv[KW][i] : zv[KW][i];                                 \
+        if (TAP == 0 && cb == 0) fetch_params(ct);                                                              \
+        read_frags(TAP % 3, KW, 0, 0);                                                                          \
+        read_frags(TAP % 3, KW, 1, 1);                                                                          \
+        mfma_group(0);                                                                                          \
+        if (TAP < 7) w_stage(cur, TAP + 2, cbs, (TAP + 2) % 3); else w_stage(nx, TAP - 7, ncbs, (TAP + 2) % 3); \
+        read_frags(TAP % 3, KW, 2, 0);                                                                          \
+        mfma_group(1);                                                                                          \
+        if ((KW) < 2) {                                                                                         \
+            const int slot2 = (xs == 0) ? 1 : 0;                                                                \
+            _Pragma("unroll") for (int q = (KW) * 5; q < ((KW) == 0 ? 5 : NQ + 1); ++q) {                       \
+                if ((KH) < 2) x_piece(cur, q, (KH) + 1, cbs, slot2); else x_piece(nx, q, 0, ncbs, slot2);       \
+            }                                                                                                   \
+        }                                                                                                       \
+        read_frags(TAP % 3, KW, 3, 1);                                                                          \
+        mfma_group(0);                                                                                          \
+        if (TAP == 8 && cb == cpt - 1 && has_res) issue_residual_loads(m0, c0);                                 \
+        mfma_group(1);                                                                                          \
+        if ((KW) == 2) xs = (xs == 0) ? XSLOT : 0;                                                              \
+        if (TAP == 0 && cb == 0) store_params();                                                                \
+    } while (0)
+
         for (int cb = 0; cb < cpt; ++cb) {
             const int cbs = cb << 7;
             const bool inner = cb + 1 < cpt;
@@ -335,18 +389,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < MP; ++i) asm volatile("" : "+v"(pv[kw][i]), "+v"(zv[kw][i]));
             asm volatile("" : "+v"(cur.xg), "+v"(cur.xg32), "+v"(nx.xg), "+v"(nx.xg32));
-            LEAN_STEP(0, 0);
-            if (cb == 0 && ct == t0) stamp(p.stamps, 3);
-            LEAN_STEP(0, 1);
-            LEAN_STEP(0, 2);
-            LEAN_STEP(1, 0);
-            LEAN_STEP(1, 1);
-            LEAN_STEP(1, 2);
-            LEAN_STEP(2, 0);
-            LEAN_STEP(2, 1);
-            LEAN_STEP(2, 2);
+            if constexpr (NXS == 3) {
+                LEAN_STEP(0, 0);
+                if (cb == 0 && ct == t0) stamp(p.stamps, 3);
+                LEAN_STEP(0, 1);
+                LEAN_STEP(0, 2);
+                LEAN_STEP(1, 0);
+                LEAN_STEP(1, 1);
+                LEAN_STEP(1, 2);
+                LEAN_STEP(2, 0);
+                LEAN_STEP(2, 1);
+                LEAN_STEP(2, 2);
+            } else {
+                LEAN2_STEP(0, 0);
+                if (cb == 0 && ct == t0) stamp(p.stamps, 3);
+                LEAN2_STEP(0, 1);
+                LEAN2_STEP(0, 2);
+                LEAN2_STEP(1, 0);
+                LEAN2_STEP(1, 1);
+                LEAN2_STEP(1, 2);
+                LEAN2_STEP(2, 0);
+                LEAN2_STEP(2, 1);
+                LEAN2_STEP(2, 2);
+            }
         }
 #undef LEAN_STEP
+#undef LEAN2_STEP
         if (ct == t0) stamp(p.stamps, 4);
 
         run_epilogue(m0, c0);
@@ -356,14 +424,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
     stamp(p.stamps, 6);
 }
 
-template <int TC, int WP, int WC, bool F8>
+template <int TC, int WP, int WC, bool F8, int TP>
 static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
-    p.n_ptiles = (p.M + 255) / 256;
+    p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = 3 * 264 * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
+    const int lds = (TP == 256 ? 3 : 2) * (TP + 8) * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
     static bool attr_set[64] = {};
-    auto kern = conv3x3_lean_kernel<TC, WP, WC, F8>;
+    auto kern = conv3x3_lean_kernel<TC, WP, WC, F8, TP>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -384,10 +452,11 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
     if (p.flags & FRP_FLAG_F8) {                   // fp8 operands: whole 128-channel rows, 128-cout tiles only
         if ((p.Cin & 127) || !p.wscale) return hipErrorInvalidValue;
-        return launch_lean_cfg<128, 4, 2, true>(p, stream);
+        return launch_lean_cfg<128, 4, 2, true, 256>(p, stream);
     }
-    if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false>(p, stream);
-    return launch_lean_cfg<64, 8, 1, false>(p, stream);
+    if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false, 256>(p, stream);
+    if (p.dbg & 128) return launch_lean_cfg<64, 8, 1, false, 256>(p, stream);      // A/B: the 256-pixel tile (1.5 reads per MFMA)
+    return launch_lean_cfg<64, 8, 1, false, 512>(p, stream);
 }
 
 }  // namespace frp

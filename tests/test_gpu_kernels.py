@@ -59,6 +59,13 @@ CONV_CASES = [
     (2, 19, 21, 64, 96, 3, 1, 0, False, 0),     # Cout = 96: ragged cout tile
     (1, 1, 1, 64, 64, 3, 1, 0, False, 0),       # single pixel: every tap but the centre is padding
     (2, 2, 2, 128, 32, 3, 1, 1, False, 0),
+    # 512 x 64 tile of the lean kernel (Cout <= 64: two-slot patch ring): ragged third tile, image rows longer than the
+    # tile, two channel blocks with Cout = 32, ten images per tile with border bias + residual + PReLU, exactly one tile
+    (3, 20, 20, 64, 64, 3, 1, 1, True, 0),
+    (1, 2, 600, 64, 64, 3, 1, 0, False, 0),
+    (2, 30, 33, 128, 32, 3, 1, 1, False, 0),
+    (70, 7, 7, 64, 64, 3, 1, 2, True, 1),
+    (2, 16, 16, 192, 64, 3, 1, 2, False, 1),    # M = 512: one full tile, three channel blocks
 ]
 
 
