@@ -109,7 +109,9 @@ class Gallery(Mapping):
 
     def reading(self):
         """Shared access for a reader that resolves device rows to names: like `locked()` it keeps updates out between
-        its device call and its lookup, but several such readers (the lanes of a GPU) may be inside together."""
+        its device call and its lookup, but several such readers (the lanes of a GPU) may be inside together.
+        Not re-entrant, and a reader must not ask for `locked()` (or anything that takes it: put / remove / `G[name]`)
+        while inside: the exclusive side waits for all readers, itself included."""
         return _Reading(self._lock)
 
     # ---- Mapping view (values are fetched from the device on demand)
