@@ -16,6 +16,7 @@
 // winners go to HBM and a second tiny kernel reduces them.  Algorithmic bytes = N*512*2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "frp_internal.h"
 
 namespace frp {
@@ -130,6 +131,138 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchParams p) {
     }
 }
 
+// Top-1 only, M <= 512 queries (the streaming path: 320 faces per step): PERSISTENT workgroups of eight waves (one per CU;
+// a query tile in LDS serves 256 gallery rows) with the running winner of every query kept in REGISTERS across all the
+// gallery blocks a wave visits.  The first kernel above reduces each 32-query tile across its four waves through LDS and
+// writes a partial winner per workgroup and tile to HBM (two barriers, ~80 compare/select instructions and 20 MB of
+// partials per million rows); here a tile costs its 32 MFMAs, a 16-way max and - only in the lanes whose tile maximum
+// beats their running best, which becomes rare after the first few blocks - the index search.  One barrier per tile (the
+// query-tile DMA), one cross-wave reduction per launch.  1 M rows x 320 queries: 0.48 ms against 0.64 (2.1 TB/s of
+// gallery = 0.69 PFLOP/s; like the conv kernels it reads one LDS fragment per MFMA, and that ratio - not the HBM
+// stream, not the accumulator chain, not the query DMA: a second accumulator, a staggered start and four-wave
+// workgroups all measured the same - is what bounds it).
+// Ties: a lane meets its rows in increasing order (blocks in increasing order, rows of a block in increasing order) and
+// replaces its winner only on a strictly greater score; half-waves, waves and workgroups are merged by (score desc,
+// row asc) - the same total order as the first kernel and the oracle, and bit-identical results.
+#define MT_MAXQT 16
+#define MT_NW 8            // waves per workgroup: one query tile in LDS serves 256 gallery rows
+__global__ __launch_bounds__(64 * MT_NW, 2) void match_top1_kernel(MatchParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char qs0[MT_Q * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char qs1[MT_Q * 1024];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nqt = p.Mpad / MT_Q;                                  // <= MT_MAXQT (launch_match)
+    const long nb = (p.N + 31) / 32;                                // 32-row gallery blocks
+    const long wstride = (long)gridDim.x * MT_NW;
+    const long rounds = (nb + wstride - 1) / wstride;               // the same for every wave: they share the barriers
+
+    const int qbase = q_lds_off(fr, fh);
+    float best[MT_MAXQT];
+    int bidx[MT_MAXQT];
+#pragma unroll
+    for (int i = 0; i < MT_MAXQT; ++i) { best[i] = -3.0f; bidx[i] = 0x7fffffff; }
+
+    auto q_dma = [&](int qt, unsigned char* buf) {
+        // (opaque tile index: the 16 x 8 source addresses of a round are the same in every round, and the compiler would
+        // rather keep 256 registers of them than recompute eight per tile)
+        int qto = qt;
+        asm volatile("" : "+s"(qto));
+        const _Float16* qp = p.q + (long)qto * MT_Q * MD;
+#pragma unroll
+        for (int i = 0; i < MT_Q / MT_NW; ++i) {
+            const int row = wave * (MT_Q / MT_NW) + i;
+            const _Float16* src = qp + (long)row * MD + ((lane ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + row * 1024), 16, 0, 0);
+        }
+    };
+
+    for (long r = 0; r < rounds; ++r) {
+        const long g0 = (r * wstride + (long)blockIdx.x * MT_NW + wave) * 32;     // may lie beyond N: every row masked then
+        const bool ragged = g0 + 32 > p.N;
+        half8 gf[32];
+        {
+            long row = g0 + fr;
+            if (row >= p.N) row = p.N - 1;
+            const _Float16* gp = p.gallery + row * MD + fh * 8;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) gf[s] = *reinterpret_cast<const half8*>(gp + s * 16);
+        }
+        q_dma(0, qs0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int qt = 0; qt < MT_MAXQT; ++qt) {
+            if (qt < nqt) {
+                const bool odd = qt & 1;
+                if (qt + 1 < nqt) { if (odd) q_dma(qt + 1, qs0); else q_dma(qt + 1, qs1); }
+                floatx16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const unsigned char* buf = odd ? qs1 : qs0;
+                // fragment s of this lane sits at qbase ^ (s << 5) (q_lds_off: chunk 2s + fh, xor-swizzled by fr & 15).
+                // One address register made opaque per tile - else all 32 addresses are hoisted out of the loops and
+                // held in registers, which the 32 running winners need
+                int qa = qbase;
+                asm volatile("" : "+v"(qa));
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    const half8 qf = *reinterpret_cast<const half8*>(&buf[qa ^ (s << 5)]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf[s], qf, acc, 0, 0, 0);
+                    // (fragment reads stay within their group of 8: left alone the scheduler hoists all 32 - 128 registers -
+                    // and the 32 running winners no longer fit)
+                    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                // acc[e]: gallery row (e&3) + 8*(e>>2) + 4*fh of this wave's 32 (increasing in e), query column fr
+                if (ragged) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (g0 + (e & 3) + 8 * (e >> 2) + 4 * fh >= p.N) acc[e] = -3.0f;
+                }
+                float tm = acc[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) tm = fmaxf(tm, acc[e]);
+                if (tm > best[qt]) {                    // rare after the first blocks: most tiles stop here
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (acc[e] > best[qt]) { best[qt] = acc[e]; bidx[qt] = (int)(g0 + (e & 3) + 8 * (e >> 2) + 4 * fh); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's DMA has had this tile to land
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // ---- one reduction per launch: half-waves, then the four waves through LDS (the query buffers are free now)
+    float* red_cos = reinterpret_cast<float*>(qs0);                  // [MT_NW][Mpad]: 16 KiB at most
+    int* red_idx = reinterpret_cast<int*>(qs1);
+#pragma unroll
+    for (int qt = 0; qt < MT_MAXQT; ++qt) {
+        if (qt < nqt) {
+            float b = best[qt];
+            int bi = bidx[qt];
+            const float ob = __shfl_xor(b, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+            if (lane < 32) { red_cos[wave * p.Mpad + qt * MT_Q + fr] = b; red_idx[wave * p.Mpad + qt * MT_Q + fr] = bi; }
+        }
+    }
+    __syncthreads();
+    for (int q = t; q < p.Mpad; q += 64 * MT_NW) {
+        float bc = red_cos[q];
+        int bi = red_idx[q];
+#pragma unroll
+        for (int w = 1; w < MT_NW; ++w) {
+            const float c = red_cos[w * p.Mpad + q];
+            const int i = red_idx[w * p.Mpad + q];
+            if (c > bc || (c == bc && i < bi)) { bc = c; bi = i; }
+        }
+        p.part_cos[(long)blockIdx.x * p.Mpad + q] = bc;
+        p.part_idx[(long)blockIdx.x * p.Mpad + q] = bi;
+    }
+}
+
 // one wave per query: reduce the per-workgroup partials
 __global__ __launch_bounds__(256) void match_reduce_kernel(MatchParams p) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -154,6 +287,17 @@ __global__ __launch_bounds__(256) void match_reduce_kernel(MatchParams p) {
     }
 }
 
+static int match_cu_count(int dev) {
+    static int cached[64] = {};
+    if (dev < 0 || dev >= 64) return 0;
+    if (cached[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 int match_num_workgroups(long N) { return (int)((N + MT_G - 1) / MT_G); }
 
 hipError_t launch_match(const MatchParams& p, hipStream_t stream) {
@@ -161,10 +305,23 @@ hipError_t launch_match(const MatchParams& p, hipStream_t stream) {
         return hipErrorInvalidValue;
     if (p.Mpad % MT_Q != 0 || p.Mpad < p.M || p.n_wg != match_num_workgroups(p.N) || p.N > 0x7fffff00L)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(match_kernel, dim3(p.n_wg), dim3(256), 0, stream, p);
+    MatchParams r = p;
+    int dev = 0;
+    if (!p.all_scores && p.Mpad <= MT_MAXQT * MT_Q && !getenv("FRP_MATCH_V1") && hipGetDevice(&dev) == hipSuccess) {
+        // top-1 for a streaming batch: persistent workgroups, running winners in registers; its partials are the first
+        // `grid` rows of the buffers the caller sized for the per-tile kernel (grid <= n_wg)
+        const int ncu = match_cu_count(dev);
+        const long want = ((p.N + 31) / 32 + MT_NW - 1) / MT_NW;
+        const int grid = (int)(want < (long)ncu ? want : (long)ncu);          // 8 waves x ~220 registers: one workgroup per CU
+        if (ncu <= 0 || grid <= 0 || grid > p.n_wg) return hipErrorInvalidValue;
+        r.n_wg = grid;
+        hipLaunchKernelGGL(match_top1_kernel, dim3(grid), dim3(64 * MT_NW), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(match_kernel, dim3(p.n_wg), dim3(256), 0, stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(match_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, stream, r);
     return hipGetLastError();
 }
 

@@ -449,6 +449,32 @@ def test_match_topk_parity(engine, N, M, k):
         assert list(idx[0, :3]) == [3, 700, 701]
 
 
+@pytest.mark.parametrize("N,M", [(1, 1), (31, 5), (1000, 33), (4097, 320), (70001, 512), (300, 513)])
+def test_match_running_best_kernel_equals_per_tile_kernel(engine, monkeypatch, N, M):
+    """the persistent top-1 kernel (running winners in registers, M <= 512) and the per-tile kernel (FRP_MATCH_V1=1; also
+    what M = 513 falls back to) return the same bits: same winner, same cosine, ties to the lower row - including
+    galleries smaller than one block, ragged last blocks and duplicate rows spread over blocks, waves and workgroups"""
+    rng = np.random.default_rng(N * 1000 + M)
+    G = rng.standard_normal((N, 512)).astype(np.float32)
+    if N > 64:
+        G[N - 1] = G[7]                      # duplicates far apart: the lower row must win
+        G[N // 2] = G[7]
+    engine.gallery_set(G)
+    Q = rng.standard_normal((M, 512)).astype(np.float32)
+    if N > 64:
+        Q[0] = G[7]
+    a_idx, a_cos = engine.match(Q)
+    monkeypatch.setenv("FRP_MATCH_V1", "1")
+    b_idx, b_cos = engine.match(Q)
+    assert np.array_equal(a_idx, b_idx) and np.array_equal(a_cos.view(np.uint32), b_cos.view(np.uint32))
+    if N > 64:
+        assert a_idx[0] == 7
+    g16 = engine.gallery_get().astype(np.float64)
+    qn = Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True)
+    S = qn.astype(np.float16).astype(np.float64) @ g16.T
+    assert np.abs(a_cos - S.max(1)).max() < 1e-3
+
+
 def test_match_topk_rejects_bad_k(engine):
     from frp_amd.native import FrpError
     engine.gallery_set(np.eye(4, 512, dtype=np.float32))
