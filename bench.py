@@ -115,37 +115,81 @@ def run_config4(args, json_fd):
     B, K, N, H, W = args.batch if args.batch != 32 else 4, args.faces, 1_000_000, 2160, 3840
     scales = (1.0, 0.5, 0.25)
     raw = weights.make_synthetic_raw(7)
-    eng = native.Engine(0, max_batch=B, max_faces=K, max_h=H, max_w=W, profile=True)
-    eng.load_weights(weights.pack_blob(raw))
-    eng.gallery_set(gallery_rows(N, 0, N))
+    L = max(1, args.lanes)
+    blob4 = weights.pack_blob(raw)
+    g4 = gallery_rows(N, 0, N)
     frames = synth_frames(B, H, W, K, 4321)
+    lanes = []
+    for _ in range(L):                          # independent handles: the host-side merge of one batch runs under the
+        e_ = native.Engine(0, max_batch=B, max_faces=K, max_h=H, max_w=W, profile=(L == 1))     # other batch's kernels
+        e_.load_weights(blob4)
+        e_.gallery_set(g4)
+        e_.upload_frames(frames)
+        lanes.append(e_)
+    del g4
+    eng = lanes[0]
     # synthetic weights: calibrate the score threshold so that about K faces per frame survive the merge
-    eng.upload_frames(frames)
     probe = eng.detect_resident((H, W), max_faces=64, det_thresh=1e-6, nms_iou=0.4)
     kth = np.sort(probe["scores"], axis=1)[:, ::-1][:, K - 1]
     thr = float(np.clip(np.median(kth[kth > 0]) if np.any(kth > 0) else 0.5, 1e-4, 0.9999))
 
-    def step():
+    def step(e_):
         per = []
         for sc in scales:
             hw = pyramid.scaled_size(H, W, sc)
-            per.append((hw, eng.detect_resident(hw, max_faces=64, det_thresh=thr, nms_iou=0.4)))
+            per.append((hw, e_.detect_resident(hw, max_faces=64, det_thresh=thr, nms_iou=0.4)))
         boxes, kps, scores, counts = pyramid.merge_scales(per, (H, W), K, 0.4)
-        return eng.finish_faces(boxes, kps, scores, counts, K)
+        return e_.finish_faces(boxes, kps, scores, counts, K)
 
-    with eng.sequence():
-        for _ in range(args.warmup):
-            step()
-        eng.synchronize()
-        eng.reset_counters()
-        t0 = time.perf_counter()
-        n_faces = 0
-        for _ in range(args.steps):
-            out = step()
-            n_faces += int(out["counts"].sum())
-        eng.synchronize()
-        dt = time.perf_counter() - t0
-    ctr = eng.counters()
+    import threading
+    faces_of = [0] * L
+
+    def lane_loop(i, counter, n_steps):
+        with lanes[i].sequence():
+            while True:
+                with counter["lock"]:
+                    if counter["next"] >= n_steps:
+                        return
+                    counter["next"] += 1
+                faces_of[i] += int(step(lanes[i])["counts"].sum())
+
+    def run_steps(n_steps):
+        counter = {"next": 0, "lock": threading.Lock()}
+        th = [threading.Thread(target=lane_loop, args=(i, counter, n_steps)) for i in range(L)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+
+    # the stage times come from one batch at a time on lane 0 (kernels of two lanes share the chip otherwise)
+    single = None
+    if L > 1:
+        eng.set_profile(True)
+        with eng.sequence():
+            step(eng)
+            eng.reset_counters()
+            eng.synchronize()
+            t_s = time.perf_counter()
+            n_s = sum(int(step(eng)["counts"].sum()) for _ in range(args.steps))
+            eng.synchronize()
+            dt_s = time.perf_counter() - t_s
+        single = {"faces_per_s": round(n_s / dt_s, 1), "ms_per_step": round(dt_s / args.steps * 1e3, 3)}
+        ctr = eng.counters()
+        eng.set_profile(False)
+    run_steps(args.warmup)
+    for e_ in lanes:
+        e_.synchronize()
+        if L == 1:
+            e_.reset_counters()
+    faces_of = [0] * L
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    for e_ in lanes:
+        e_.synchronize()
+    dt = time.perf_counter() - t0
+    n_faces = sum(faces_of)
+    if L == 1:
+        ctr = eng.counters()
     conv_ms = ctr["ms_det_conv"] + ctr["ms_emb_conv"]
     conv_flops = ctr["det_conv_flops"] + ctr["emb_conv_flops"]
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -158,6 +202,7 @@ def run_config4(args, json_fd):
         "config": {"workload": f"{B}x{H}x{W} BGR frames resident in HBM per step, pyramid scales {scales}, threshold mode "
                                f"(det_thresh {thr:.4f} calibrated to ~{K} faces/frame, NMS 0.4, host merge across scales), "
                                f"{N}-identity fp16 gallery, host results out every step",
+                   "lanes": L, "one_batch_at_a_time": single,
                    "frames_per_s": round(args.steps * B / dt, 2), "faces_per_frame_mean": round(n_faces / (args.steps * B), 2),
                    "gflop_per_frame_detect_all_scales": round(ctr["det_conv_flops"] / max(1, args.steps * B) / 1e9, 1),
                    "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in
@@ -169,7 +214,8 @@ def run_config4(args, json_fd):
                                       "bytes_per_launch": N * 512 * 2}},
     }
     os.write(json_fd, (json.dumps(line) + "\n").encode())
-    eng.close()
+    for e_ in lanes:
+        e_.close()
 
 
 def main():
