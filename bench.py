@@ -97,8 +97,8 @@ def cpu_baseline(raw, frames, K, n_gallery, sample_frames):
     res = onet.process_frames(raw, fr, None, canvas, score_thresh=0.0, nms_iou=2.0, max_faces=K)
     t_net = time.perf_counter() - t0
     n_faces = sum(len(r["emb"]) for r in res)
-    # reference plumbing at the same gallery size, timed on 2 faces and scaled
-    t_face = plumbing.time_reference_plumbing(n_gallery, 512, 2)
+    # reference plumbing at the same gallery size, timed on 8 faces and scaled
+    t_face = plumbing.time_reference_plumbing(n_gallery, 512, 8)
     total = t_net + t_face * n_faces
     return {"value": round(n_faces / total, 3), "unit": "faces/s", "cores": cores, "kind": "port",
             "sample": f"{sample_frames}x1080p frames, {n_faces} faces: fp32 torch-CPU oracle network {t_net:.2f}s "
@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="batches in flight per GPU in the timed region (one C-ABI handle = one stream each; 1 = strictly one "
                          "batch at a time)")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (0 = skip); the default is ~10-15 s of CPU work")
     ap.add_argument("--pcie-steps", type=int, default=-1,
                     help="steps of the host-to-host side measurement (-1 = as many as --steps, 0 = skip)")
     ap.add_argument("--threshold-steps", type=int, default=-1,
