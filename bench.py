@@ -422,6 +422,42 @@ def main():
         h2h_lanes = {"faces_per_s": round(n_h * B * K / dt_h, 1), "ms_per_step": round(dt_h / n_h * 1e3, 3), "steps": n_h,
                      "mode": f"{L} lanes, each running the overlapped-ingest loop (page-locked host frames, H2D on the lane's copy "
                              "stream under the kernels of both lanes, host results out every step)"}
+    # Threshold mode on the lanes (never `value`): score threshold + NMS + ragged face counts, the path the reference's
+    # loop runs; one lane's mid-pipeline host round trip (the 4-byte face count) hides under the other lane's kernels.
+    thr_lanes = None
+    if L > 1 and args.threshold_steps != 0 and rank == 0:
+        n_t = args.steps if args.threshold_steps < 0 else args.threshold_steps
+        probe = lanes[0].detect(frames, max_faces=64, det_thresh=1e-6, nms_iou=0.4)
+        kth = np.sort(probe["scores"], axis=1)[:, ::-1][:, min(K, 63) - 1]
+        dthr = float(np.clip(np.median(kth[kth > 0]) if np.any(kth > 0) else 0.5, 1e-4, 0.9999))
+        faces_l = [0] * L
+        for e_ in lanes:
+            e_.upload_frames(frames)
+            e_.process_resident(K, det_thresh=dthr, nms_iou=0.4, flags=0)
+            e_.fetch_results()
+
+        def lane_loop_thr(i, counter):
+            while True:
+                with counter["lock"]:
+                    if counter["next"] >= n_t:
+                        return
+                    counter["next"] += 1
+                lanes[i].process_resident(K, det_thresh=dthr, nms_iou=0.4, flags=0)
+                faces_l[i] += int(lanes[i].fetch_results()["counts"].sum())
+
+        counter = {"next": 0, "lock": threading.Lock()}
+        th = [threading.Thread(target=lane_loop_thr, args=(i, counter)) for i in range(L)]
+        t_t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt_t = time.perf_counter() - t_t
+        thr_lanes = {"faces_per_s": round(sum(faces_l) / dt_t, 1), "frames_per_s": round(n_t * B / dt_t, 1),
+                     "ms_per_step": round(dt_t / n_t * 1e3, 3), "steps": n_t, "det_thresh": round(dthr, 6), "nms_iou": 0.4,
+                     "mode": f"{L} lanes, resident frames, score threshold + NMS + ragged face counts, host results out every step"}
+        for e_ in lanes:
+            e_.upload_frames(frames)
     done_ = [r_ for r_ in last if r_ is not None]
     assert done_ and all(np.all(r_["counts"] == K) for r_ in done_)
     res = done_[0]
@@ -519,7 +555,7 @@ def main():
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
                        "lanes": L, "one_batch_at_a_time": single,
                        "host_to_host": pcie, "host_to_host_lanes": h2h_lanes,
-                       "threshold_mode": thr,
+                       "threshold_mode": thr, "threshold_mode_lanes": thr_lanes,
                        "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
                        "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),
                        "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in

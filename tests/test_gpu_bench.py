@@ -35,7 +35,7 @@ def test_bench_line_contract(lanes):
     assert cfg["lanes"] == lanes and "workload" in cfg and cfg["batch_frames"] == 2 and cfg["gallery"] == 2000
     assert (cfg["one_batch_at_a_time"] is None) == (lanes == 1)
     assert cfg["host_to_host"]["ms_per_step"] > 0 and cfg["threshold_mode"]["steps"] == 3
-    assert (cfg["host_to_host_lanes"] is None) == (lanes == 1)
+    assert (cfg["host_to_host_lanes"] is None) == (lanes == 1) and (cfg["threshold_mode_lanes"] is None) == (lanes == 1)
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_source_sha256_16", "measured_on"):
         assert key in rf, key
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
