@@ -153,13 +153,23 @@ def run_config4(args, json_fd):
                     counter["next"] += 1
                 faces_of[i] += int(step(lanes[i])["counts"].sum())
 
+    lane_errors = []
+
+    def guarded_loop(i, counter, n_steps):        # a lane thread's exception must fail the bench
+        try:
+            lane_loop(i, counter, n_steps)
+        except BaseException as ex:                # noqa: BLE001
+            lane_errors.append(ex)
+
     def run_steps(n_steps):
         counter = {"next": 0, "lock": threading.Lock()}
-        th = [threading.Thread(target=lane_loop, args=(i, counter, n_steps)) for i in range(L)]
+        th = [threading.Thread(target=guarded_loop, args=(i, counter, n_steps)) for i in range(L)]
         for x in th:
             x.start()
         for x in th:
             x.join()
+        if lane_errors:
+            raise lane_errors[0]
 
     # the stage times come from one batch at a time on lane 0 (kernels of two lanes share the chip otherwise)
     single = None
@@ -348,6 +358,25 @@ def main():
     import threading
     last = [None] * L
 
+    lane_errors = []
+
+    def guarded(fn):
+        """a lane thread's exception must fail the bench, not silently drop the steps that thread had taken"""
+        def run(*a):
+            try:
+                fn(*a)
+            except BaseException as ex:      # noqa: BLE001
+                lane_errors.append(ex)
+        return run
+
+    def join_lanes(th):
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if lane_errors:
+            raise lane_errors[0]
+
     def lane_loop(i, counter, n_steps):
         while True:
             with counter["lock"]:
@@ -362,11 +391,7 @@ def main():
         if L == 1:
             lane_loop(0, counter, n_steps)
             return
-        th = [threading.Thread(target=lane_loop, args=(i, counter, n_steps)) for i in range(L)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        join_lanes([threading.Thread(target=guarded(lane_loop), args=(i, counter, n_steps)) for i in range(L)])
 
     if L > 1:
         run_steps(args.warmup)          # the lanes' own warm-up: W steps submitted exactly like the timed ones
@@ -410,12 +435,8 @@ def main():
         for e_ in lanes:
             e_.synchronize()
         counter = {"next": 0, "lock": threading.Lock()}
-        th = [threading.Thread(target=lane_loop_h2h, args=(i, counter)) for i in range(L)]
         t_h = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        join_lanes([threading.Thread(target=guarded(lane_loop_h2h), args=(i, counter)) for i in range(L)])
         for e_ in lanes:
             e_.synchronize()
         dt_h = time.perf_counter() - t_h
@@ -446,12 +467,8 @@ def main():
                 faces_l[i] += int(lanes[i].fetch_results()["counts"].sum())
 
         counter = {"next": 0, "lock": threading.Lock()}
-        th = [threading.Thread(target=lane_loop_thr, args=(i, counter)) for i in range(L)]
         t_t = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        join_lanes([threading.Thread(target=guarded(lane_loop_thr), args=(i, counter)) for i in range(L)])
         dt_t = time.perf_counter() - t_t
         thr_lanes = {"faces_per_s": round(sum(faces_l) / dt_t, 1), "frames_per_s": round(n_t * B / dt_t, 1),
                      "ms_per_step": round(dt_t / n_t * 1e3, 3), "steps": n_t, "det_thresh": round(dthr, 6), "nms_iou": 0.4,
