@@ -1022,7 +1022,8 @@ void frp_host_free(frp_handle* h, void* p) {
 
 int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride) {
     if (!h) return FRP_ERR_INVALID;
-    Guard g(h);
+    Guard g(h, false);      // copy stream only: does not re-record the stage events, so a pending pass is not drained
+                            // (with the timers on, settling here made the upload of batch t+1 wait for batch t)
     if (!bgr || B <= 0 || H <= 0 || W <= 0 || row_stride < (int64_t)W * 3) return fail(h, FRP_ERR_INVALID, "bad frame arguments");
     if (B > 1024) return fail(h, FRP_ERR_INVALID, "batch too large (max 1024 frames per call)");
     const size_t need = (size_t)B * H * W * 3;
@@ -1044,7 +1045,7 @@ int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_
 
 int frp_swap_frames(frp_handle* h) {
     if (!h) return FRP_ERR_INVALID;
-    Guard g(h);
+    Guard g(h, false);      // enqueues a wait + an event on the compute stream; the stage events stay as recorded
     if (!h->next_valid) return fail(h, FRP_ERR_INVALID, "no staged frames (call frp_upload_frames_async)");
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_next_ready, 0));     // compute waits for the staged copy
     std::swap(h->frames, h->frames_next);
@@ -1612,7 +1613,7 @@ int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops) 
     if (rc != FRP_OK) return rc;
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("kstep_lab: ") + hipGetErrorString(e));
     // fp8 variants (bit 10): 8 MFMAs of 32x32x64 per wave and step = twice the FLOPs of the fp16 step
-    *tflops = (float)((double)blocks * 8.0 * 16 * kstep_lab_steps_per_iter(variant) * iters * 32768.0 * ((variant & 1024) ? 2.0 : 1.0) /
+    *tflops = (float)((double)blocks * kstep_lab_waves(variant) * 16 * kstep_lab_steps_per_iter(variant) * iters * 32768.0 * ((variant & 1024) ? 2.0 : 1.0) /
                       (ms * 1e-3) / 1e12);
     return FRP_OK;
 }

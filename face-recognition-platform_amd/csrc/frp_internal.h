@@ -147,6 +147,7 @@ hipError_t launch_mfma_lds(const _Float16* src, float* dst, int blocks, int read
 // tuning lab: schedules of the conv k-step's inner loop in isolation (kstep_lab.hip)
 hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int variant, int iters, hipStream_t stream);
 int kstep_lab_steps_per_iter(int variant);
+int kstep_lab_waves(int variant);
 hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream);
 
 // K6: cosine match, top-1 (and optional full score matrix)

@@ -33,7 +33,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import native
+from . import lanes, native
 from .gallery import Gallery
 
 logger = logging.getLogger(__name__)
@@ -155,8 +155,12 @@ class FaceService:
                     if len(self.ENCODINGS) > 0 or getattr(self, "_blob_loaded", None) is None:
                         return None
                     e2 = native.Engine(self._device)
-                    e2.load_weights(self._blob_loaded)
-                    self.ENCODINGS.add_mirror(e2)
+                    try:
+                        e2.load_weights(self._blob_loaded)
+                        self.ENCODINGS.add_mirror(e2)      # raises if an enrolment slipped in since the check above
+                    except Exception:
+                        e2.close()
+                        return None
                     self._engine2 = e2
         return self._engine2
 
@@ -353,37 +357,35 @@ class FaceService:
 
     # ------------------------------------------------------------------ store / delete (:344-390, :517-547)
     def store_face(self, target_name: str, encoding: np.ndarray) -> Dict[str, Any]:
+        """:344-390.  The exclusive gallery lock (which stalls every streaming lane) is held for the duplicate scan and for
+        the insert only; the storage write (DB round trip) and the on-disk backup run outside it, in the reference's order:
+        scan -> store_embedding -> ENCODINGS[name] = ... -> backup."""
         try:
             enc = np.asarray(encoding, dtype=np.float64).reshape(-1)
             is_dup, similar = False, None
-            with self.ENCODINGS.locked():
-                return self._store_face_locked(target_name, enc, is_dup, similar)
+            with self.ENCODINGS.locked():          # scan and `already` against ONE gallery state
+                if len(self.ENCODINGS):
+                    names, d = self._distances(enc)
+                    for n, dist in zip(names, d):          # first hit in dict order, as :353-364
+                        if n != target_name and dist < 0.3:
+                            is_dup, similar = True, n
+                            logger.warning("Potential duplicate: %s ~ %s (distance=%.3f)", target_name, n, dist)
+                            break
+            if not self._storage.store_embedding(target_name, enc.tolist()):
+                return {"success": False, "message": "Failed to store in database", "is_duplicate": is_dup}
+            already = self.ENCODINGS.put(target_name, enc)     # exclusive inside; reaches every lane's copy
+            try:
+                self._backup_encoding_atomic(target_name, enc.tolist())
+            except Exception as be:
+                logger.warning("Backup failed for %s: %s", target_name, be)
+            message = f"Face {'updated' if already else 'stored'} successfully for '{target_name}'"
+            if is_dup:
+                message += f" (Warning: Similar to '{similar}')"
+            return {"success": True, "message": message, "is_duplicate": is_dup,
+                    "similar_to": similar if is_dup else None, "was_update": already}
         except Exception as e:
             logger.exception("Error storing face %s: %s", target_name, e)
             return {"success": False, "message": f"Error storing face: {str(e)}", "is_duplicate": False}
-
-    def _store_face_locked(self, target_name: str, enc: np.ndarray, is_dup: bool, similar) -> Dict[str, Any]:
-        """duplicate scan + insert against ONE gallery state (caller holds the gallery lock)"""
-        if len(self.ENCODINGS):
-            names, d = self._distances(enc)
-            for n, dist in zip(names, d):          # first hit in dict order, as :353-364
-                if n != target_name and dist < 0.3:
-                    is_dup, similar = True, n
-                    logger.warning("Potential duplicate: %s ~ %s (distance=%.3f)", target_name, n, dist)
-                    break
-        already = target_name in self.ENCODINGS
-        if not self._storage.store_embedding(target_name, enc.tolist()):
-            return {"success": False, "message": "Failed to store in database", "is_duplicate": is_dup}
-        self.ENCODINGS.put(target_name, enc)
-        try:
-            self._backup_encoding_atomic(target_name, enc.tolist())
-        except Exception as be:
-            logger.warning("Backup failed for %s: %s", target_name, be)
-        message = f"Face {'updated' if already else 'stored'} successfully for '{target_name}'"
-        if is_dup:
-            message += f" (Warning: Similar to '{similar}')"
-        return {"success": True, "message": message, "is_duplicate": is_dup,
-                "similar_to": similar if is_dup else None, "was_update": already}
 
     def delete_face(self, target_name: str) -> Dict[str, Any]:
         try:
@@ -594,64 +596,9 @@ class FaceService:
         e2 = self._eng2()
         if e2 is not None:
             engines.append(e2)
-        it = iter(batches)
-        cv = threading.Condition()
-        st = {"next": 0, "yielded": 0, "done": {}, "exhausted": False, "error": None}
-        n = len(engines)
-
-        def worker(eng):
-            while True:
-                with cv:
-                    while st["next"] - st["yielded"] >= 2 * n and st["error"] is None and not st["exhausted"]:
-                        cv.wait()
-                    if st["exhausted"] or st["error"] is not None:
-                        return
-                    try:
-                        frames = next(it)
-                    except StopIteration:
-                        st["exhausted"] = True
-                        cv.notify_all()
-                        return
-                    except BaseException as ex:
-                        st["error"] = ex
-                        cv.notify_all()
-                        return
-                    t = st["next"]
-                    st["next"] += 1
-                try:
-                    out = self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold, det_thresh, all_matches)
-                except BaseException as ex:
-                    with cv:
-                        st["error"] = ex
-                        cv.notify_all()
-                    return
-                with cv:
-                    st["done"][t] = out
-                    cv.notify_all()
-
-        threads = [threading.Thread(target=worker, args=(e,), daemon=True) for e in engines]
-        for th in threads:
-            th.start()
-        try:
-            while True:
-                with cv:
-                    while (st["yielded"] not in st["done"] and st["error"] is None
-                           and not (st["exhausted"] and st["yielded"] >= st["next"])):
-                        cv.wait()
-                    if st["error"] is not None:
-                        raise st["error"]
-                    if st["yielded"] not in st["done"]:
-                        return
-                    out = st["done"].pop(st["yielded"])
-                    st["yielded"] += 1
-                    cv.notify_all()
-                yield out
-        finally:
-            with cv:
-                st["exhausted"] = True
-                cv.notify_all()
-            for th in threads:
-                th.join()
+        def on(eng):
+            return lambda frames: self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold, det_thresh, all_matches)
+        return lanes.run_ordered(batches, [on(e) for e in engines])
 
     def process_frame(self, frame_bgr_or_path, metadata: Optional[Dict[str, Any]] = None):
         if isinstance(frame_bgr_or_path, str):

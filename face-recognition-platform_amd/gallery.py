@@ -153,13 +153,28 @@ class Gallery(Mapping):
         """insert or overwrite; returns True if the name already existed."""
         with self._lock:
             e = np.asarray(emb, dtype=np.float32).reshape(-1)
+            engines = self._engines()
             if name in self._rows:
-                for eng in self._engines():
-                    eng.gallery_update_row(self._rows[name], e)
+                row = self._rows[name]
+                old = None
+                for i, eng in enumerate(engines):
+                    try:
+                        if i == 0 and len(engines) > 1:
+                            old = eng.gallery_get(row, 1)[0].astype(np.float32)      # the stored unit row, for the rollback
+                        eng.gallery_update_row(row, e)
+                    except Exception:
+                        for done in engines[:i]:            # a later copy failed: the copies must not differ by a row
+                            done.gallery_update_row(row, old)
+                        raise
                 return True
             row = len(self._names)
-            for eng in self._engines():
-                eng.gallery_update_row(row, e)         # row == size appends
+            for i, eng in enumerate(engines):
+                try:
+                    eng.gallery_update_row(row, e)         # row == size appends
+                except Exception:
+                    for done in engines[:i]:
+                        done.gallery_remove_row(row)
+                    raise
             self._rows[name] = row
             self._names.append(name)
             return False
@@ -168,16 +183,36 @@ class Gallery(Mapping):
         with self._lock:
             if name not in self._rows:
                 return False
-            row = self._rows.pop(name)
+            row = self._rows[name]
             last = len(self._names) - 1
-            for eng in self._engines():
-                eng.gallery_remove_row(row)            # device: last row moves into `row`
+            engines = self._engines()
+            try:
+                for eng in engines:
+                    eng.gallery_remove_row(row)        # device: last row moves into `row`
+            except Exception:
+                # a copy failed half way (the swap already happened on the earlier ones): the removal is abandoned and
+                # every copy is brought back to the rows the name table still lists
+                self._resync_from(engines)
+                raise
+            self._rows.pop(name)
             if row != last:
                 moved = self._names[last]
                 self._names[row] = moved
                 self._rows[moved] = row                # dict position (insertion order) is unchanged
             self._names.pop()
             return True
+
+    def _resync_from(self, engines) -> None:
+        """after a failed multi-copy update: make every copy equal to the name table again (rows the table still
+        lists, read back from whichever copy still has `len(names)` rows)"""
+        n = len(self._names)
+        src = next((e for e in engines if e.gallery_size() == n), None)
+        if src is None:
+            return
+        rows = src.gallery_get(0, n).astype(np.float32) if n else np.zeros((0, 512), np.float32)
+        for e in engines:
+            if e is not src:
+                e.gallery_set(rows)
 
     def set_bulk(self, names: List[str], emb: np.ndarray):
         """replace the whole gallery (startup load / all-gathered watchlist)."""

@@ -34,6 +34,12 @@ def decode_rgb(src: Source, hw: Tuple[int, int]) -> np.ndarray:
     return img
 
 
+def batched(sources: Sequence[Source], batch: int) -> Iterator[Sequence[Source]]:
+    """an upload of any length as consecutive batches of at most `batch` stills (what StagedIngest.run consumes)"""
+    for i in range(0, len(sources), batch):
+        yield sources[i:i + batch]
+
+
 class StagedIngest:
     """Two page-locked staging buffers of B x H x W RGB frames on one engine."""
 
@@ -42,9 +48,12 @@ class StagedIngest:
         self._stage = [engine.host_frames(batch, height, width) for _ in range(2)]
 
     def decode_into(self, slot: int, sources: Sequence[Source]) -> int:
-        """decode up to B stills into staging buffer `slot`; frames beyond len(sources) are zeroed.  -> count"""
+        """decode up to B stills into staging buffer `slot`; frames beyond len(sources) are zeroed.  -> count.
+        More than B sources is an error (nothing is dropped silently): chunk the upload with `batched()`."""
         buf = self._stage[slot]
-        n = min(len(sources), self.B)
+        n = len(sources)
+        if n > self.B:
+            raise ValueError(f"{n} images for a staging buffer of {self.B}: split the upload into batches (ingest.batched)")
         for i in range(n):
             np.copyto(buf[i], decode_rgb(sources[i], (self.H, self.W)))
         if n < self.B:

@@ -18,11 +18,80 @@ results are handed back in submission order, at most `n_lanes` batches later.
 from __future__ import annotations
 
 import threading
-from typing import Dict, Iterable, Iterator, List
+from typing import Any, Callable, Dict, Iterable, Iterator, List, Sequence
 
 import numpy as np
 
 from . import native
+
+
+def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[[Any], Any]]) -> Iterator[Any]:
+    """The one in-order, bounded-look-ahead pipeline behind Lanes.run and FaceService.process_stream: `workers[i]` (one
+    host thread each) turn items of `batches` into results; results are yielded in submission order; at most
+    2 x len(workers) items are taken ahead of the consumer.  An exception of the iterator or of a worker is raised in
+    the consumer.  When the consumer abandons the generator (close(), break, an exception in its loop body) every
+    worker - also one parked on the look-ahead throttle - leaves after the item it is working on: the throttle's
+    wait tests `exhausted` too (it did not: a consumer slower than the device that stopped early hung in join())."""
+    it = iter(batches)
+    n = len(workers)
+    if n < 1:
+        raise ValueError("run_ordered needs at least one worker")
+    cv = threading.Condition()
+    st = {"next": 0, "yielded": 0, "done": {}, "exhausted": False, "error": None}
+
+    def loop(fn: Callable[[Any], Any]) -> None:
+        while True:
+            with cv:
+                while st["next"] - st["yielded"] >= 2 * n and st["error"] is None and not st["exhausted"]:
+                    cv.wait()
+                if st["exhausted"] or st["error"] is not None:
+                    return
+                try:
+                    item = next(it)
+                except StopIteration:
+                    st["exhausted"] = True
+                    cv.notify_all()
+                    return
+                except BaseException as ex:      # the caller's iterator failed: surface it in the consumer
+                    st["error"] = ex
+                    cv.notify_all()
+                    return
+                t = st["next"]
+                st["next"] += 1
+            try:
+                out = fn(item)
+            except BaseException as ex:
+                with cv:
+                    st["error"] = ex
+                    cv.notify_all()
+                return
+            with cv:
+                st["done"][t] = out
+                cv.notify_all()
+
+    threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]
+    for th in threads:
+        th.start()
+    try:
+        while True:
+            with cv:
+                while (st["yielded"] not in st["done"] and st["error"] is None
+                       and not (st["exhausted"] and st["yielded"] >= st["next"])):
+                    cv.wait()
+                if st["error"] is not None:
+                    raise st["error"]
+                if st["yielded"] not in st["done"]:
+                    return
+                out = st["done"].pop(st["yielded"])
+                st["yielded"] += 1
+                cv.notify_all()
+            yield out
+    finally:
+        with cv:
+            st["exhausted"] = True       # consumer gone (or done): workers stop after their current item
+            cv.notify_all()
+        for th in threads:
+            th.join()
 
 
 class Lanes:
@@ -56,61 +125,6 @@ class Lanes:
         """detect + embed + match every batch of host frames [B,H,W,3]; yields the result dicts in submission order.
         Batch t+1 is pulled from `batches` and runs on another lane while batch t is on the device; at most
         2 x n_lanes batches are taken ahead of the consumer."""
-        it = iter(batches)
-        n = len(self.engines)
-        cv = threading.Condition()
-        state = {"next": 0, "done": {}, "exhausted": False, "error": None, "yielded": 0}
-
-        def worker(e: native.Engine) -> None:
-            while True:
-                with cv:
-                    while state["next"] - state["yielded"] >= 2 * n and state["error"] is None:
-                        cv.wait()
-                    if state["exhausted"] or state["error"] is not None:
-                        return
-                    try:
-                        frames = next(it)
-                    except StopIteration:
-                        state["exhausted"] = True
-                        cv.notify_all()
-                        return
-                    except BaseException as ex:      # the caller's iterator failed: surface it in run()
-                        state["error"] = ex
-                        cv.notify_all()
-                        return
-                    t = state["next"]
-                    state["next"] += 1
-                try:
-                    out = e.process_frames(frames, max_faces=max_faces, det_thresh=det_thresh, nms_iou=nms_iou, flags=flags)
-                except BaseException as ex:
-                    with cv:
-                        state["error"] = ex
-                        cv.notify_all()
-                    return
-                with cv:
-                    state["done"][t] = out
-                    cv.notify_all()
-
-        threads = [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
-        for th in threads:
-            th.start()
-        try:
-            while True:
-                with cv:
-                    while (state["yielded"] not in state["done"] and state["error"] is None
-                           and not (state["exhausted"] and state["yielded"] >= state["next"])):
-                        cv.wait()
-                    if state["error"] is not None:
-                        raise state["error"]
-                    if state["yielded"] not in state["done"]:
-                        return
-                    out = state["done"].pop(state["yielded"])
-                    state["yielded"] += 1
-                    cv.notify_all()
-                yield out
-        finally:
-            with cv:
-                state["exhausted"] = True       # consumer gone (or done): workers stop after their current batch
-                cv.notify_all()
-            for th in threads:
-                th.join()
+        def on(e: native.Engine):
+            return lambda frames: e.process_frames(frames, max_faces=max_faces, det_thresh=det_thresh, nms_iou=nms_iou, flags=flags)
+        return run_ordered(batches, [on(e) for e in self.engines])

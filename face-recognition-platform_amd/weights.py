@@ -99,8 +99,9 @@ def _bn_affine(raw, name) -> Tuple[np.ndarray, np.ndarray]:
     return s, b - m * s
 
 
-def fold_layer(raw: Dict[str, np.ndarray], l: ns.ConvLayer):
-    """-> (w fp16 [cout][k][k][cin], bias fp32 [cout] or [9][cout], slope fp32 [cout] or None)"""
+def fold_layer(raw: Dict[str, np.ndarray], l: ns.ConvLayer, return_w64: bool = False):
+    """-> (w fp16 [cout][k][k][cin], bias fp32 [cout] or [9][cout], slope fp32 [cout] or None)
+    `return_w64` appends the folded weights before the fp16 cast (float64, same layout, padded channels zero)."""
     cin_r = l.cin_real or l.cin
     cout_r = l.cout_real or l.cout
     if l.name == "emb.fc":
@@ -143,15 +144,18 @@ def fold_layer(raw: Dict[str, np.ndarray], l: ns.ConvLayer):
     if l.name == "emb.fc":
         # -> [cout][y][x][c] flattened: matches the NHWC [7,7,512] activation viewed as 1x1x25088
         Wp = np.transpose(W, (0, 2, 3, 1)).reshape(cout_r, 1, 1, 7 * 7 * 512)
-        w16 = np.zeros((l.cout, 1, 1, l.cin), dtype=np.float16)
-        w16[:cout_r] = Wp.astype(np.float16)
+        w64 = np.zeros((l.cout, 1, 1, l.cin), dtype=np.float64)
+        w64[:cout_r] = Wp
     else:
-        w16 = np.zeros((l.cout, l.k, l.k, l.cin), dtype=np.float16)
-        w16[:cout_r, :, :, :cin_r] = np.transpose(W, (0, 2, 3, 1)).astype(np.float16)
+        w64 = np.zeros((l.cout, l.k, l.k, l.cin), dtype=np.float64)
+        w64[:cout_r, :, :, :cin_r] = np.transpose(W, (0, 2, 3, 1))
+    w16 = w64.astype(np.float16)
     slope = None
     if l.act == ns.ACT_PRELU:
         slope = np.zeros((l.cout,), dtype=np.float32)
         slope[:cout_r] = raw[l.prelu + ".weight"]
+    if return_w64:
+        return w16, bias.astype(np.float32), slope, w64
     return w16, bias.astype(np.float32), slope
 
 
@@ -264,11 +268,115 @@ def fp8_dequantize_rows(codes: np.ndarray, scale: np.ndarray) -> np.ndarray:
     return v.astype(np.float32).astype(np.float16).reshape(codes.shape)
 
 
+def run_program_fp32(raw: Dict[str, np.ndarray], layers: List[ns.ConvLayer], x: "np.ndarray", fp16_storage: bool = True,
+                     weights_of=None, want_amax: bool = False):
+    """The folded conv program on the CPU (torch fp32 convolutions): the arithmetic the device runs up to summation
+    order when `fp16_storage` (fp16-rounded weights, every activation rounded to fp16 between layers), or the same
+    program in plain fp32.  x: NHWC float array holding the network input.  `weights_of(layer, w16) -> array` may
+    substitute a layer's folded weights (tests: the fp8-dequantised ones).  -> output of the last layer (NHWC / [N, D]),
+    and with `want_amax` the dict tensor name -> max |value| over the batch (the fp8 calibration statistic)."""
+    import torch
+    import torch.nn.functional as F
+    tens = {layers[0].src: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).permute(0, 3, 1, 2)}
+    amax = {}
+    with torch.no_grad():
+        for l in layers:
+            w16, bias, slope = fold_layer(raw, l)
+            w = w16 if weights_of is None else weights_of(l, w16)
+            t = tens[l.src]
+            if l.flags & ns.FLAG_FLATTEN:
+                t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, 1, 1)
+            y = F.conv2d(t, torch.from_numpy(np.asarray(w, dtype=np.float32)).permute(0, 3, 1, 2), None, stride=l.stride, padding=l.k // 2)
+            Ho, Wo = y.shape[2], y.shape[3]
+            if l.flags & ns.FLAG_BORDER_BIAS:
+                cy = np.where(np.arange(Ho) == 0, 0, np.where(np.arange(Ho) == Ho - 1, 2, 1))
+                cx = np.where(np.arange(Wo) == 0, 0, np.where(np.arange(Wo) == Wo - 1, 2, 1))
+                y = y + torch.from_numpy(bias[cy[:, None] * 3 + cx[None, :]]).permute(2, 0, 1)[None]
+            else:
+                y = y + torch.from_numpy(bias)[None, :, None, None]
+            if l.res:
+                r = tens[l.res]
+                if l.flags & ns.FLAG_RES_UP2:
+                    r = r.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+                y = y + r
+            if l.act == ns.ACT_RELU:
+                y = torch.relu(y)
+            elif l.act == ns.ACT_PRELU:
+                y = torch.where(y > 0, y, y * torch.from_numpy(slope)[None, :, None, None])
+            if fp16_storage and not (l.flags & ns.FLAG_OUT_F32):
+                y = y.half().float()
+            tens[l.dst] = y
+            if want_amax:
+                amax[l.dst] = float(y.abs().max())
+    out = tens[layers[-1].dst]
+    out = out.reshape(out.shape[0], -1).numpy() if (layers[-1].flags & ns.FLAG_FLATTEN) else out.permute(0, 2, 3, 1).numpy()
+    return (out, amax) if want_amax else out
+
+
+FP8_HEADROOM = 2.0      # calibration maps the largest observed |activation| to 448 / FP8_HEADROOM (E4M3 is floating point:
+                        # headroom costs no relative precision until values reach the subnormal range, 2^-6 of the scale)
+
+
+def default_calibration_chips(n: int = 4, seed: int = 1234) -> np.ndarray:
+    """seeded aligned-chip stand-ins [n,112,112,3] u8 BGR (no face crops exist offline): smooth low-frequency content +
+    noise, so that the activation statistics are not those of white noise alone.  Real packs: pass real aligned chips."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, ns.EMB_SIZE), np.linspace(-1, 1, ns.EMB_SIZE), indexing="ij")
+    chips = np.empty((n, ns.EMB_SIZE, ns.EMB_SIZE, 3), np.float64)
+    for i in range(n):
+        c = rng.uniform(-0.3, 0.3, 2)
+        blob = np.exp(-(((xx - c[0]) / 0.55) ** 2 + ((yy - c[1]) / 0.7) ** 2))
+        base = rng.uniform(60, 120, 3)[None, None, :] + blob[..., None] * rng.uniform(40, 110, 3)[None, None, :]
+        chips[i] = base + rng.standard_normal((ns.EMB_SIZE, ns.EMB_SIZE, 3)) * rng.uniform(6, 40)
+    return np.clip(np.rint(chips), 0, 255).astype(np.uint8)
+
+
+def emb_input_blob(chips_bgr: np.ndarray) -> np.ndarray:
+    """aligned chips [n,112,112,3] u8 BGR -> the embedder's NHWC8 input as the device builds it: RGB (x - 127.5) / 127.5
+    rounded to fp16, channels 3..7 zero"""
+    x = np.zeros((len(chips_bgr), ns.EMB_SIZE, ns.EMB_SIZE, ns.EMB_IN_CH), np.float32)
+    x[..., :3] = ((chips_bgr[..., ::-1].astype(np.float32) - 127.5) / 127.5).astype(np.float16)
+    return x
+
+
+def calibrate_fp8(raw: Dict[str, np.ndarray], layers: List[ns.ConvLayer], plan, chips_bgr: np.ndarray = None) -> Dict[str, float]:
+    """Per-tensor scales of the fp8 activations of an embedder program: the fp16 program runs on the calibration chips
+    (CPU emulation, run_program_fp32), every tensor that exists in E4M3 (the primary output of an `out8` op, the `dst2`
+    copy of an fp16 output) gets scale = 2^ceil(log2(FP8_HEADROOM * amax / 448)).  Powers of two: scaling a tensor by a
+    power of two then moves its scale and leaves its codes - and the network's result - bit for bit unchanged.
+    -> tensor name -> scale (the stored byte is value / scale)."""
+    if chips_bgr is None:
+        chips_bgr = default_calibration_chips()
+    _, amax = run_program_fp32(raw, layers, emb_input_blob(chips_bgr), True, want_amax=True)
+    scales = {}
+    for l, pl in zip(layers, plan):
+        if pl["out8"] or pl["dst2"]:
+            a = amax[l.dst]
+            scales[l.dst] = float(2.0 ** np.ceil(np.log2(FP8_HEADROOM * a / 448.0))) if a > 0 and np.isfinite(a) else 1.0
+    return scales
+
+
+def fp8_dequantized_weights(layers: List[ns.ConvLayer], plan):
+    """`weights_of` hook for run_program_fp32: the folded weights of the fp8 ops replaced by what their E4M3 codes
+    decode to (value = table[code] * per-cout scale, NOT re-rounded to fp16: that is what the matrix unit multiplies)"""
+    f8 = {l.name for l, pl in zip(layers, plan) if pl["f8"]}
+
+    def hook(l, w16):
+        if l.name not in f8:
+            return w16.astype(np.float32)
+        codes, scale = fp8_quantize_rows(w16)
+        return (FP8_E4M3[codes.reshape(codes.shape[0], -1)] * scale[:, None]).reshape(codes.shape).astype(np.float32)
+    return hook
+
+
 def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3, 13, 30, 3),
-              weight_format: str = "fp16", w16_hook=None) -> bytes:
+              weight_format: str = "fp16", w16_hook=None, calib_chips: np.ndarray = None, calibrate: bool = True) -> bytes:
     """weight_format "fp8": conv/FC weights are stored as E4M3 bytes + one fp32 scale per output channel
     (half the blob, half the upload); the library expands them to fp16 at load, the kernels are the fp16
-    ones.  `w16_hook(layer, w16) -> w16` lets tests substitute the folded fp16 weights of a layer."""
+    ones.  "fp8-mfma": the eligible embedder convs also run on E4M3 ACTIVATIONS; their per-tensor scales come from a
+    calibration pass of the fp16 program over `calib_chips` (aligned chips [n,112,112,3] u8 BGR; default: seeded
+    stand-ins) - `calibrate=False` writes unit scales (tests: what an uncalibrated pack does to scaled activations).
+    `w16_hook(layer, w16) -> w16` lets tests substitute the folded fp16 weights of a layer."""
     if weight_format not in ("fp16", "fp8", "fp8-mfma"):
         raise ValueError("weight_format must be 'fp16', 'fp8' (storage only) or 'fp8-mfma' (fp8 storage + fp8 matrix path for the embedder)")
     det = ns.detector_layers(det_blocks)
@@ -285,6 +393,7 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
     def pack_ops(layers, pinned, fp8_mfma=False):
         import copy
         plan = plan_fp8(layers) if fp8_mfma else [{"f8": False, "out8": False, "dst2": None}] * len(layers)
+        scales = calibrate_fp8(raw, layers, plan, calib_chips) if (fp8_mfma and calibrate) else {}
         view = []                                   # the layer list as the buffer planner sees it (fp8 tensors by name)
         for l, pl in zip(layers, plan):
             v = copy.copy(l)
@@ -316,7 +425,9 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
             ops += struct.pack(OP_FMT, phys[v.src], phys[l.dst], phys[l.res] if l.res else -1,
                                l.cin, l.cout, l.k, l.stride, l.act, flags,
                                (l.cin_real or l.cin) | ((l.cout_real or l.cout) << 16), w_off, b_off, s_off,
-                               phys[v.dst2] if v.dst2 else -1, 1.0, 1.0, 0)
+                               phys[v.dst2] if v.dst2 else -1,
+                               scales.get(l.src, 1.0) if pl["f8"] else 1.0,                         # scale of the fp8 tensor it reads
+                               scales.get(l.dst, 1.0) if (pl["out8"] or pl["dst2"]) else 1.0, 0)    # ... and of the one it writes
         return bytes(ops), phys, nb
 
     det_ops, det_phys, det_nb = pack_ops(det, ["det.in", "det.out3", "det.out4", "det.out5"])

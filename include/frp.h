@@ -227,8 +227,9 @@ int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops);
  * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */
 int frp_get_counters(frp_handle* h, frp_counters* out);
 int frp_reset_counters(frp_handle* h);
-/* switch the per-stage HIP-event timing (frp_config.profile) on or off: with it on, every process call ends in a stream
- * synchronise so that the events can be read */
+/* switch the per-stage HIP-event timing (frp_config.profile) on or off.  frp_process_resident leaves its events unread; they
+ * are read by the next call that waits for the stream anyway (frp_fetch_results, frp_synchronize) or, with a wait of its own,
+ * by the first other call that would re-record them.  frp_upload_frames_async / frp_swap_frames never wait for them. */
 int frp_set_profile(frp_handle* h, int32_t on);
 
 #ifdef __cplusplus

@@ -37,3 +37,20 @@ def get_raw_and_blob(det_blocks, emb_blocks, seed=7):
         raw = weights.make_synthetic_raw(seed, det_blocks, emb_blocks)
         _BLOBS[key] = (raw, weights.pack_blob(raw, det_blocks, emb_blocks))
     return _BLOBS[key]
+
+
+def rescaled_embedder_raw(raw, emb_blocks, factor, stages=(2, 3, 4)):
+    """An embedder that computes the SAME function with its inner activations `factor` times larger: in every block of
+    `stages` the BatchNorm after conv1 (bn2: gamma and beta) is multiplied by `factor` - PReLU is positively
+    homogeneous, so the tensor conv2 reads grows by exactly that factor - and conv2's weights are divided by it.
+    With a power-of-two factor every fp16 / fp32 quantity scales exactly.  Used to show that the fp8 activation scales
+    are calibrated (an uncalibrated E4M3 tensor saturates at 448 or flushes to zero when its range moves)."""
+    import numpy as np
+    out = dict(raw)
+    for li in stages:
+        for bi in range(emb_blocks[li - 1]):
+            p = f"emb.layer{li}.{bi}"
+            out[p + ".bn2.weight"] = raw[p + ".bn2.weight"] * np.float32(factor)
+            out[p + ".bn2.bias"] = raw[p + ".bn2.bias"] * np.float32(factor)
+            out[p + ".conv2.weight"] = raw[p + ".conv2.weight"] / np.float32(factor)
+    return out

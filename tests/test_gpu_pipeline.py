@@ -414,17 +414,30 @@ def test_fp8_weight_blob(engine):
         assert np.array_equal(idx, np.arange(100, 100 + len(e16)))
 
 
+def _unit(x):
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
 def test_fp8_mfma_embedder(engine):
     """BASELINE config 5 ("fp8 ArcFace weights (CDNA4 fp8 MFMA)"): the embedder blob packed with weight_format
     "fp8-mfma" runs every eligible 3x3 conv of stages 2-4 on E4M3 ACTIVATIONS and WEIGHTS through the block-scaled fp8
-    MFMA kernel (the residual stream stays fp16; fp8 copies are written by the producing epilogues).  Bars (SURVEY 8c,
-    fp8): top-1 identity identical; embedding cosine against (a) the fp32 oracle on the fp8-DEQUANTISED weights and
-    (b) the fp16 path >= 0.97 (measured: ~0.99 on the seeded R100; activations carry 3 mantissa bits)."""
+    MFMA kernel (the residual stream stays fp16; fp8 copies are written by the producing epilogues; per-tensor activation
+    scales from the calibration pass in weights.calibrate_fp8).  Compared with
+      (a) the program in fp32 on the fp8-DEQUANTISED weights of exactly those layers (weights.fp8_dequantized_weights;
+          the other layers keep their fp16-rounded weights): what is left is the E4M3 rounding of the activations;
+      (b) the fp32 oracle network on the original weights (weights + activations);
+      (c) the fp16 path of the library.
+    Bars: top-1 identity identical among 5,000 distractors; cosine >= 0.985 against all three
+    (measured on the seeded R100: see the assertion message / DESIGN.md; E4M3 carries 3 mantissa bits and the error
+    of ~90 fp8 layers accumulates in the residual stream - decisions near the thresholds: test_fp8_decision_flips)."""
     from frp_amd import weights as wts
     rng = np.random.default_rng(58)
     chips = rng.integers(0, 256, size=(8, 112, 112, 3), dtype=np.uint8)
+    floors = {}
     for det_blocks, emb_blocks in [((1, 1, 1, 1), (1, 2, 2, 1)), ((1, 1, 1, 1), (3, 13, 30, 3))]:
         raw = wts.make_synthetic_raw(19, det_blocks, emb_blocks)
+        layers = wts.ns.iresnet_layers(emb_blocks)
+        plan = wts.plan_fp8(layers)
         blob8 = wts.pack_blob(raw, det_blocks, emb_blocks, weight_format="fp8-mfma")
         engine.load_weights(wts.pack_blob(raw, det_blocks, emb_blocks))
         e16 = engine.embed_aligned(chips)
@@ -432,20 +445,153 @@ def test_fp8_mfma_embedder(engine):
         engine.reset_counters()
         e8 = engine.embed_aligned(chips)
         ctr = engine.counters()
-        n_f8 = sum(1 for l, pl in zip(wts.ns.iresnet_layers(emb_blocks), wts.plan_fp8(wts.ns.iresnet_layers(emb_blocks))) if pl["f8"])
+        n_f8 = sum(1 for pl in plan if pl["f8"])
         assert ctr["f8_conv_launches"] == n_f8 > 0                     # the fp8 kernel really ran, on every planned layer
         assert np.abs(np.linalg.norm(e8, axis=1) - 1).max() < 1e-4
-        # oracle: fp32 network on the dequantised fp8 weights of the SAME layers (others keep their fp16-rounded weights)
-        raw_dq = dict(raw)
-        ref = onet.emb_forward(raw_dq, onet.emb_blob(chips))
-        cos16 = (e8 * e16).sum(1)
-        cosref = (e8 * ref).sum(1)
-        assert cos16.min() > 0.97 and cosref.min() > 0.97, (cos16.min(), cosref.min())
+        ref_dq = _unit(wts.run_program_fp32(raw, layers, wts.emb_input_blob(chips), fp16_storage=False,
+                                            weights_of=wts.fp8_dequantized_weights(layers, plan)))
+        ref = onet.emb_forward(raw, onet.emb_blob(chips))
+        # the dequantised-weight reference really differs from the plain one (it did not, when it was a plain copy)
+        assert 1e-4 < 1 - (ref_dq * ref).sum(1).min() < 2e-2
+        cos_dq, cos_ref, cos16 = (e8 * ref_dq).sum(1), (e8 * ref).sum(1), (e8 * e16).sum(1)
+        floors[emb_blocks] = (float(cos_dq.min()), float(cos_ref.min()), float(cos16.min()))
+        assert min(floors[emb_blocks]) > 0.985, floors
+        assert cos_dq.min() >= cos_ref.min() - 2e-3, floors           # weight rounding removed: not further away
         G = rng.standard_normal((5000, 512)).astype(np.float32)
         G[200:200 + len(e16)] = e16
         engine.gallery_set(G)
         idx, _ = engine.match(e8)
         assert np.array_equal(idx, np.arange(200, 200 + len(e16)))       # identical top-1 identity
+    print("fp8-mfma cosine floors (vs dequantised-weight fp32 program, vs fp32 oracle, vs fp16 path):", floors)
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_fp8_activation_scales_follow_the_tensor_range(engine):
+    """The calibration has teeth: the SAME embedder function with its inner activations 256 x larger / 64 x smaller
+    (conftest.rescaled_embedder_raw: bn2 scaled, conv2 divided).  Calibrated blobs: the fp8 tensors hold the same codes, the
+    embedding does not move (cos >= 1 - 2e-4 against the unscaled fp8 run; not bit-exact only because the rescaled conv
+    weights become fp16 subnormals).  Uncalibrated blobs (unit scales, what pack_blob wrote before): 256 x saturates
+    E4M3 at 448, 1/64 x drops the tensor into the subnormal codes - the embedding leaves."""
+    from conftest import rescaled_embedder_raw
+    from frp_amd import weights as wts
+    rng = np.random.default_rng(59)
+    chips = rng.integers(0, 256, size=(6, 112, 112, 3), dtype=np.uint8)
+    blocks = (2, 3, 4, 2)
+    raw = wts.make_synthetic_raw(23, (1, 1, 1, 1), blocks)
+    engine.load_weights(wts.pack_blob(raw, (1, 1, 1, 1), blocks, weight_format="fp8-mfma"))
+    base = engine.embed_aligned(chips)
+    engine.load_weights(wts.pack_blob(raw, (1, 1, 1, 1), blocks))
+    e16 = engine.embed_aligned(chips)
+    assert (base * e16).sum(1).min() > 0.985
+    moved = {}
+    for f in (256.0, 1.0 / 64):
+        raw_f = rescaled_embedder_raw(raw, blocks, f)
+        engine.load_weights(wts.pack_blob(raw_f, (1, 1, 1, 1), blocks))
+        assert (engine.embed_aligned(chips) * e16).sum(1).min() > 1 - 1e-4        # the same function (fp16 path)
+        engine.load_weights(wts.pack_blob(raw_f, (1, 1, 1, 1), blocks, weight_format="fp8-mfma"))
+        cal = engine.embed_aligned(chips)
+        engine.load_weights(wts.pack_blob(raw_f, (1, 1, 1, 1), blocks, weight_format="fp8-mfma", calibrate=False))
+        unc = engine.embed_aligned(chips)
+        moved[f] = (float((cal * base).sum(1).min()), float((unc * base).sum(1).min()))
+        assert moved[f][0] > 1 - 2e-4, moved
+        assert moved[f][1] < 0.97, moved
+    print("calibrated / uncalibrated cosine vs the unscaled fp8 run:", moved)
+
+
+def _planted_rows(e, dists, rng):
+    """unit rows at exact Euclidean distances `dists` [M, R] from the unit vectors e [M, 512] (random directions)"""
+    M, R = dists.shape
+    u = rng.standard_normal((M, R, 512))
+    u -= (u * e[:, None, :]).sum(-1, keepdims=True) * e[:, None, :]
+    u /= np.linalg.norm(u, axis=-1, keepdims=True)
+    c = 1.0 - dists.astype(np.float64) ** 2 / 2.0
+    return (c[..., None] * e[:, None, :] + np.sqrt(1.0 - c ** 2)[..., None] * u).astype(np.float32)
+
+
+def test_fp8_decision_flips_near_thresholds(engine):
+    """What the fp8 path's embedding drift means for the reference's DECISIONS (face_service.py:43,411 match d <= 0.6;
+    :486-492 buckets at 0.4 / 0.6; :352-364 duplicate gate d < 0.3): for 48 faces, gallery rows planted at distance
+    threshold -+ delta of the fp16 embedding, delta in {0.01, 0.02, 0.05, 0.1}; a decision FLIPS when the fp8 embedding
+    puts the row on the other side of the threshold.  Bar: no flip at delta >= 0.05 (the measured drift of a distance is
+    below 0.03); the flip counts at 0.01 / 0.02 are printed (DESIGN.md quotes them)."""
+    from frp_amd import weights as wts
+    rng = np.random.default_rng(61)
+    chips = rng.integers(0, 256, size=(48, 112, 112, 3), dtype=np.uint8)
+    blocks = (3, 13, 30, 3)
+    raw = wts.make_synthetic_raw(19, (1, 1, 1, 1), blocks)
+    engine.load_weights(wts.pack_blob(raw, (1, 1, 1, 1), blocks))
+    e16 = engine.embed_aligned(chips)
+    engine.load_weights(wts.pack_blob(raw, (1, 1, 1, 1), blocks, weight_format="fp8-mfma"))
+    e8 = engine.embed_aligned(chips)
+    deltas = np.array([0.01, 0.02, 0.05, 0.1])
+    thr = np.array([0.3, 0.4, 0.6])
+    signed = np.concatenate([-deltas[::-1], deltas])                                   # 8 offsets per threshold
+    dists = np.tile((thr[:, None] + signed[None, :]).reshape(1, -1), (len(chips), 1))    # [M, 24]
+    rows = _planted_rows(e16.astype(np.float64), dists, rng).reshape(-1, 512)
+    engine.gallery_set(rows)
+    stored = engine.gallery_get(0, len(rows)).astype(np.float64)                        # the unit fp16 rows the device matches
+    R = dists.shape[1]
+    flips = np.zeros((len(thr), len(signed)), int)
+    drift = []
+    for q, name in ((e16, "fp16"), (e8, "fp8")):
+        cos = engine.match_scores(q)                                                     # [M, M*R]
+        d = onet.cos_to_distance(np.stack([cos[i, i * R:(i + 1) * R] for i in range(len(chips))]))
+        if name == "fp16":
+            d16 = d
+            # the planted geometry survives the fp16 gallery: every row is on the side it was planted on
+            assert np.all((d16 < np.repeat(thr, len(signed))[None]) == (dists < np.repeat(thr, len(signed))[None]))
+        else:
+            drift = np.abs(d - d16)
+            for ti, t in enumerate(thr):
+                sl = slice(ti * len(signed), (ti + 1) * len(signed))
+                flips[ti] = ((d[:, sl] < t) != (d16[:, sl] < t)).sum(0)       # 0.3: dup gate, 0.4: bucket; 0.6 below
+                if t == 0.6:
+                    flips[ti] = ((d[:, sl] <= t) != (d16[:, sl] <= t)).sum(0)  # match = d <= tolerance (:411)
+    report = {f"thr {t}": {f"{s:+.2f}": int(n) for s, n in zip(signed, flips[ti])} for ti, t in enumerate(thr)}
+    print(f"fp8 decision flips of {len(chips)} faces per planted offset:", report, "max |distance drift|", float(drift.max()),
+          "mean", float(drift.mean()), "cos(e8, e16) min", float((e8 * e16).sum(1).min()))
+    far = np.abs(signed) >= 0.05
+    assert flips[:, far].sum() == 0, report
+    assert drift.max() < 0.03, float(drift.max())
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_config5_end_to_end_720p_two_streams_fp8(engine):
+    """BASELINE configs[4] end to end: two synthetic 720p streams mixed into one batch per GPU (frame t of stream 0,
+    frame t of stream 1, ...), detector fp16, embedder on the fp8 matrix path, match against a 20 k gallery holding the
+    faces' own fp16 embeddings.  Against the fp16 blob on the same batch: boxes / landmarks / scores / counts identical
+    (the detector does not change), top-1 rows identical, embedding cosine above the fp8 bar; and the batch gives every
+    frame the result it gets alone (mixing streams into a batch changes nothing)."""
+    from frp_amd import native, weights as wts
+    rng = np.random.default_rng(62)
+    det_blocks, emb_blocks = (1, 2, 2, 2), (3, 13, 30, 3)
+    raw = wts.make_synthetic_raw(7, det_blocks, emb_blocks)
+    streams = [_frames(np.random.default_rng(100 + s), 3, 720, 1280) for s in range(2)]
+    batch = np.stack([streams[s][t] for t in range(3) for s in range(2)])             # interleaved: 6 x 720p
+    K = 5
+    engine.load_weights(wts.pack_blob(raw, det_blocks, emb_blocks))
+    engine.gallery_set(np.zeros((0, 512), np.float32))
+    o16 = engine.process_frames(batch, max_faces=K, flags=native.FLAG_FORCED_K | native.FLAG_NO_MATCH)
+    assert np.all(o16["counts"] == K)
+    G = _unit(rng.standard_normal((20000, 512))).astype(np.float32)
+    rows = rng.choice(len(G), size=batch.shape[0] * K, replace=False).reshape(batch.shape[0], K)
+    G[rows.reshape(-1)] = o16["emb"].reshape(-1, 512)
+    engine.gallery_set(G)
+    o16 = engine.process_frames(batch, max_faces=K, flags=native.FLAG_FORCED_K)
+    assert np.array_equal(o16["match_idx"], rows)
+    engine.load_weights(wts.pack_blob(raw, det_blocks, emb_blocks, weight_format="fp8-mfma"))
+    o8 = engine.process_frames(batch, max_faces=K, flags=native.FLAG_FORCED_K)
+    for k in ("boxes", "kps", "scores", "counts"):
+        assert np.array_equal(o8[k], o16[k]), k
+    assert np.array_equal(o8["match_idx"], rows)                                     # identical top-1 identity
+    cos = (o8["emb"] * o16["emb"]).sum(-1)
+    assert cos.min() > 0.985, float(cos.min())
+    assert np.abs(o8["match_cos"] - cos).max() < 2e-3                                # the matcher saw these embeddings
+    alone = engine.process_frames(streams[1][2][None], max_faces=K, flags=native.FLAG_FORCED_K)
+    for k in ("boxes", "kps", "scores", "match_idx"):
+        assert np.array_equal(alone[k][0], o8[k][5]), k                              # frame 2 of stream 1 = batch slot 5
+    assert np.abs(alone["emb"][0] - o8["emb"][5]).max() < 1e-6                        # (the FC's split-K follows the batch size)
+    print("config-5 end to end: cos(fp8, fp16) min", float(cos.min()), "mean", float(cos.mean()))
     engine.gallery_set(np.zeros((0, 512), np.float32))
 
 

@@ -339,6 +339,51 @@ def test_arcface_checkpoint_loader_roundtrip(tmp_path):
     assert blob[:8] == b"FRPBLOB1"
 
 
+def test_fp8_activation_scales_are_calibrated():
+    """BASELINE config 5: the fp8-mfma blob carries per-tensor activation scales from a calibration pass of the fp16
+    program (weights.calibrate_fp8) - not 1.0.  (1) every fp8 tensor's writer and reader agree on its scale; (2) scales
+    are powers of two that put the observed |max| inside (448 / 4, 448 / 2]; (3) an embedder whose inner activations are
+    64 x larger or smaller (same function: conftest.rescaled_embedder_raw) gets scales moved by exactly that factor."""
+    import struct
+    from conftest import rescaled_embedder_raw
+    from frp_amd import netspec as ns, weights as wts
+    blocks = (1, 2, 2, 1)
+    raw = wts.make_synthetic_raw(19, (1, 1, 1, 1), blocks)
+    layers = ns.iresnet_layers(blocks)
+    plan = wts.plan_fp8(layers)
+    chips = wts.default_calibration_chips(3)
+    sc = wts.calibrate_fp8(raw, layers, plan, chips)
+    _, amax = wts.run_program_fp32(raw, layers, wts.emb_input_blob(chips), True, want_amax=True)
+    assert sc and set(sc) == {l.dst for l, pl in zip(layers, plan) if pl["out8"] or pl["dst2"]}
+    for name, s in sc.items():
+        assert np.log2(s) == np.round(np.log2(s))
+        assert 448 / 4 < amax[name] / s * wts.FP8_HEADROOM <= 448 * 1.0001, (name, amax[name], s)
+    for f in (64.0, 1.0 / 64):
+        sc2 = wts.calibrate_fp8(rescaled_embedder_raw(raw, blocks, f), layers, plan, chips)
+        for name in sc:
+            assert sc2[name] == sc[name] * (f if name.endswith(".t") else 1.0), (name, f)
+    blob = wts.pack_blob(raw, (1, 1, 1, 1), blocks, weight_format="fp8-mfma", calib_chips=chips)
+    hdr = struct.unpack(wts.HEADER_FMT, blob[:wts.HEADER_BYTES])
+    n_emb, emb_off = hdr[11], hdr[20]
+    ops = [dict(zip(wts.OP_FIELDS, struct.unpack(wts.OP_FMT, blob[emb_off + i * wts.OP_BYTES: emb_off + (i + 1) * wts.OP_BYTES])))
+           for i in range(n_emb)]
+    written = {}                                  # physical buffer -> scale of the fp8 tensor last written there
+    n_checked = 0
+    for op, l, pl in zip(ops, layers, plan):
+        if pl["f8"]:
+            assert op["flags"] & wts.OPFLAG_FP8_MFMA and op["in_scale"] == written[op["in_buf"]] == sc[l.src]
+            n_checked += 1
+        if pl["out8"]:
+            written[op["out_buf"]] = op["out_scale"]
+        elif pl["dst2"]:
+            written[op["out2_buf"]] = op["out_scale"]
+        if pl["out8"] or pl["dst2"]:
+            assert op["out_scale"] == sc[l.dst] != 1.0
+    assert n_checked == sum(pl["f8"] for pl in plan) > 0
+    unit = wts.pack_blob(raw, (1, 1, 1, 1), blocks, weight_format="fp8-mfma", calibrate=False)
+    assert len(unit) == len(blob) and unit != blob
+
+
 def test_fp8_weight_codec_and_blob():
     """BASELINE config 5 storage format: E4M3FN codec properties and the fp8 blob layout"""
     import struct
@@ -440,6 +485,36 @@ def test_lanes_keep_submission_order_and_surface_errors(monkeypatch):
     assert all(e.closed for e in SlowEngine.made)
     with pytest.raises(ValueError):
         lanes_mod.Lanes(0, 0)
+
+
+def test_abandoned_stream_with_full_look_ahead_does_not_deadlock(monkeypatch):
+    """a consumer SLOWER than the device that stops early: the workers are parked on the look-ahead throttle when the
+    generator is closed and must leave (they used to wait there forever and close() hung in join()).  Unbounded source;
+    close() runs under a watchdog."""
+    import itertools
+    import threading
+    import time
+    from frp_amd import lanes as lanes_mod
+
+    def watchdog(fn, seconds=10.0):
+        th = threading.Thread(target=fn, daemon=True)
+        th.start()
+        th.join(seconds)
+        assert not th.is_alive(), "generator close() hung: workers parked on the throttle never woke up"
+
+    g = lanes_mod.run_ordered((np.array([t]) for t in itertools.count()), [lambda x: int(x[0])] * 2)
+    assert next(g) == 0
+    time.sleep(0.2)                      # both workers run ahead until the look-ahead (2 x 2 items) is full and park
+    watchdog(g.close)
+    # ... and when the consumer's loop body raises
+    def body():
+        with pytest.raises(ZeroDivisionError):
+            for out in lanes_mod.run_ordered((np.array([t]) for t in itertools.count()), [lambda x: int(x[0])] * 3):
+                time.sleep(0.1)
+                1 / 0
+    watchdog(body)
+    with pytest.raises(ValueError):
+        next(lanes_mod.run_ordered([1], []))
 
 
 def test_gallery_rw_lock_and_mirrors():
