@@ -475,6 +475,33 @@ def main():
                      "mode": f"{L} lanes, resident frames, score threshold + NMS + ragged face counts, host results out every step"}
         for e_ in lanes:
             e_.upload_frames(frames)
+    # The boundary the reference's callers use (never `value`): FaceService.process_stream from HOST frames (pageable memory,
+    # the blocking frp_process_frames call per batch) to the per-frame lists of per-face dicts the route hands on
+    # (routes/camera.py:243-259) - name lookup, distance, bucket and threshold included - on the same two lanes, in
+    # threshold mode (the service API has no forced-K switch).  Compare with threshold_mode_lanes (engine level, resident).
+    svc_line = None
+    if L > 1 and args.threshold_steps != 0 and rank == 0 and thr_lanes is not None:
+        from frp_amd.face_service import FaceService
+        n_s = args.steps if args.threshold_steps < 0 else args.threshold_steps
+        svc = FaceService(engine=lanes[0], second_engine=lanes[1])
+        svc.ENCODINGS.adopt_device([f"id{i:07d}" for i in range(N)])
+        for _ in svc.process_stream((frames for _ in range(2)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
+            pass
+        t_v = time.perf_counter()
+        n_faces_v = n_match_v = 0
+        for per_frame in svc.process_stream((frames for _ in range(n_s)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
+            for faces in per_frame:
+                n_faces_v += len(faces)
+                n_match_v += sum(1 for f_ in faces if f_["target"] is not None)
+        dt_v = time.perf_counter() - t_v
+        assert n_match_v == n_faces_v > 0
+        svc_line = {"faces_per_s": round(n_faces_v / dt_v, 1), "frames_per_s": round(n_s * B / dt_v, 1),
+                    "ms_per_step": round(dt_v / n_s * 1e3, 3), "steps": n_s,
+                    "fraction_of_engine_threshold_mode_lanes": round((n_faces_v / dt_v) / max(1e-9, thr_lanes["faces_per_s"]), 3),
+                    "mode": "FaceService.process_stream: pageable host frames in (blocking upload per batch), list of per-face dicts out "
+                            "(target name, distance, cosine, confidence bucket, match flag, bbox, kps, score, 512-d embedding), 2 lanes, threshold mode"}
+        for e_ in lanes:
+            e_.upload_frames(frames)
     done_ = [r_ for r_ in last if r_ is not None]
     assert done_ and all(np.all(r_["counts"] == K) for r_ in done_)
     res = done_[0]
@@ -572,7 +599,7 @@ def main():
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
                        "lanes": L, "one_batch_at_a_time": single,
                        "host_to_host": pcie, "host_to_host_lanes": h2h_lanes,
-                       "threshold_mode": thr, "threshold_mode_lanes": thr_lanes,
+                       "threshold_mode": thr, "threshold_mode_lanes": thr_lanes, "service_api": svc_line,
                        "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
                        "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),
                        "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in

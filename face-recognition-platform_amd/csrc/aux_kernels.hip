@@ -87,7 +87,7 @@ __constant__ float kTemplate[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0
 #define ALIGN_SPLIT 7
 __global__ __launch_bounds__(256) void align_kernel(AlignParams p) {
     const int f = blockIdx.x / ALIGN_SPLIT, part = blockIdx.x - f * ALIGN_SPLIT;
-    if (f >= p.n_faces) return;
+    if (f >= p.n_faces || (p.n_dev && f >= *p.n_dev)) return;
     const int slot = p.face_slot ? p.face_slot[f] : f;
     const int b = p.face_slot ? slot / p.max_faces : 0;
     const float* k = p.kps + (long)slot * 10;
@@ -202,10 +202,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _Float16* __restrict__ emb16, int M, int D,
-                                                      const float* __restrict__ partials, int ksplit, const float* __restrict__ bias) {
+                                                      const float* __restrict__ partials, int ksplit, const float* __restrict__ bias,
+                                                      const int32_t* __restrict__ n_dev, int fc_ktot, int n_cu) {
     // one workgroup per row (D <= 1024: up to 4 elements per thread in registers)
     __shared__ float wsum[4];
     const int row = blockIdx.x, t = threadIdx.x;
+    if (n_dev) {                      // the row count lives on the device: M was the capacity, the slabs are [ks][n][D]
+        const int n = *n_dev < M ? *n_dev : M;
+        if (row >= n) return;
+        M = n;
+        if (ksplit < 0) ksplit = conv_pick_ksplit(n, D, fc_ktot, FRP_FLAG_OUT_F32, false, n_cu);
+    }
     float* e = emb + (long)row * D;
     float v[4];
     float ss = 0.f;
@@ -241,10 +248,11 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ emb, _F
 }
 
 hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream, const float* partials, int ksplit,
-                         const float* bias) {
+                         const float* bias, const int32_t* n_dev, int fc_ktot, int n_cu) {
     if (M <= 0) return hipSuccess;
-    if (D <= 0 || D > 1024 || (partials && (ksplit <= 0 || !bias))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l2norm_kernel, dim3(M), dim3(256), 0, stream, emb, emb16, M, D, partials, ksplit, bias);
+    if (D <= 0 || D > 1024 || (partials && ((ksplit <= 0 && !(ksplit == -1 && n_dev && fc_ktot > 0 && n_cu > 0)) || !bias)))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(M), dim3(256), 0, stream, emb, emb16, M, D, partials, ksplit, bias, n_dev, fc_ktot, n_cu);
     return hipGetLastError();
 }
 
@@ -270,6 +278,7 @@ hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int 
     return hipGetLastError();
 }
 
+#ifdef FRP_LAB
 // ------------------------------------------------------------------ benchmark helper
 // uniform [-scale, scale) fp16 fill from a counter hash (tuning runs must use random data:
 // zero operands raise the clock and flatter the kernel)
@@ -362,5 +371,6 @@ hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scal
     hipLaunchKernelGGL(fill_random_f16_kernel, dim3(4096), dim3(256), 0, stream, p, n, seed, scale);
     return hipGetLastError();
 }
+#endif  // FRP_LAB
 
 }  // namespace frp

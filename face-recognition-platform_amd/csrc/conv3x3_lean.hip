@@ -43,8 +43,15 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // TWO slots: a row's patch is fired ONE row ahead (during the first two k-steps of the row before it: 9 pieces per wave,
 // 5 + 4), its slot is the running patch parity (a scalar, not a constant), and the counted waits change accordingly.
 template <int TC, int WP, int WC, bool F8, int TP>
-__global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p) {
+__global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    ConvParams p = p_in;
+    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+        int n = *p.n_dev;
+        n = n < 0 ? 0 : (n > p.N ? p.N : n);
+        p.M = n * p.Ho * p.Wo;
+        p.n_ptiles = (p.M + TP - 1) / TP;
+    }
     constexpr int NW = 8;
     constexpr int NXS = TP == 256 ? 3 : 2;    // patch ring slots
     constexpr int NQ = TP / 64;               // row groups (of 8 rows) per wave; one more group is shared
@@ -446,6 +453,15 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     return hipGetLastError();
+}
+
+// Shapes the row-patch kernel covers; `p` carries the derived fields of launch_conv().
+bool conv3x3_rows_eligible(const ConvParams& p) {
+    if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1) return false;
+    if (p.Ho != p.H || p.Wo != p.W) return false;
+    // signed 32-bit patch offsets: the patch of the last tile runs up to W + 264 pixels past the tensor
+    const long reach = ((long)p.M + p.W + 600) * p.Cin * 2;
+    return reach < 0x7fffffffL;
 }
 
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {

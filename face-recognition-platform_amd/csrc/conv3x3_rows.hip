@@ -552,15 +552,6 @@ static hipError_t launch_rows_cfg(const ConvParams& p0, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Shapes the row-patch kernel covers; `p` carries the derived fields of launch_conv().
-bool conv3x3_rows_eligible(const ConvParams& p) {
-    if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1) return false;
-    if (p.Ho != p.H || p.Wo != p.W) return false;
-    // signed 32-bit patch offsets: the patch of the last tile runs up to W + 264 pixels past the tensor
-    const long reach = ((long)p.M + p.W + 600) * p.Cin * 2;
-    return reach < 0x7fffffffL;
-}
-
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_rows_eligible(p)) return hipErrorInvalidValue;
     if (p.out2) return launch_conv3x3_lean(p, stream);   // the fp8-copy epilogue lives in the static-loop generation only

@@ -41,8 +41,16 @@
 namespace frp {
 
 template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
-__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ConvParams p = p_in;
+    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+        int n = *p.n_dev;
+        n = n < 0 ? 0 : (n > p.N ? p.N : n);
+        p.M = n * p.Ho * p.Wo;
+        p.n_ptiles = (p.M + TP - 1) / TP;
+        if (p.ksplit < 0) p.ksplit = conv_pick_ksplit(p.M, p.Cout, p.Ktot, p.flags, p.res != nullptr, p.n_cu);
+    }
     constexpr int XB = TP * 128;              // bytes of one X stage
     constexpr int WB = TC * 128;
     constexpr int STAGE = XB + WB;
@@ -412,10 +420,13 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    const long ntiles = (long)p.n_ptiles * p.n_ctiles * p.ksplit;
-    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
+    // (device-side split choice: the grid is sized for the largest split, that of a single image)
+    const int ks_grid = p.ksplit < 0 ? conv_pick_ksplit(p.Ho * p.Wo, p.Cout, p.Ktot, p.flags, p.res != nullptr, ncu) : p.ksplit;
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles * ks_grid;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    p.n_cu = ncu;
     // persistent: as many workgroups per CU as the LDS ring allows (1 or 2), each walks a
     // contiguous range of tiles
     const long slots = (long)ncu * (lds <= 80 * 1024 ? 2 : 1);
@@ -438,7 +449,8 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     p.M = (int)M;
     p.Ktot = p.KS * p.KS * p.Cin;
     p.nk = (p.Ktot + 63) / 64;
-    if (p.ksplit < 1) p.ksplit = 1;
+    if (p.ksplit < 0 && !(p.n_dev && (p.flags & FRP_FLAG_OUT_F32) && !p.res && !(p.Cin & 63))) return hipErrorInvalidValue;
+    if (p.ksplit == 0) p.ksplit = 1;
     if (p.ksplit > 1 && (p.nk % p.ksplit != 0 || !(p.flags & FRP_FLAG_OUT_F32) || p.res || (p.Cin & 63)))
         return hipErrorInvalidValue;             // split-K: exact slices, fp32 slabs, aligned path only
     // buffer descriptors carry 32-bit sizes and the kernel does signed 32-bit offset math
@@ -447,7 +459,7 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     const long xb = (long)p.N * p.H * p.W * p.Cin * es, wb = (long)p.Cout * p.Ktot * es;
     if (xb >= 0x7fffffffL || wb >= 0x7fffffffL) return hipErrorInvalidValue;
     if ((p.flags & FRP_FLAG_OUT_FP8) && !f8) return hipErrorInvalidValue;
-    if ((p.out2 || f8) && ((p.flags & FRP_FLAG_OUT_F32) || p.ksplit > 1 || !(p.out_scale > 0.f))) return hipErrorInvalidValue;
+    if ((p.out2 || f8) && ((p.flags & FRP_FLAG_OUT_F32) || p.ksplit != 1 || !(p.out_scale > 0.f))) return hipErrorInvalidValue;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
     const bool small = (p.Cin & 63) != 0;
@@ -466,7 +478,11 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         if (!conv3x3_rows_eligible(p) || (p.Cin & 127) || !p.wscale || !(p.in_scale > 0.f)) return hipErrorInvalidValue;
         return launch_conv3x3_lean(p, stream);
     }
+#ifdef FRP_LAB   // lab build: dbg bits select the first-generation kernel and its timing ablations (conv3x3_rows.hip)
     if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
+#else
+    if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_lean(p, stream);
+#endif
     // Tile selection (measured on MI355X, tools/conv_bench.py):
     //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one
     //               workgroup per CU).  Two independent 4-wave 128x128 groups per CU (2-slot
@@ -476,20 +492,6 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if (p.Cout > 64)
         return small ? launch_cfg<256, 128, 4, 2, 3, 8, true>(p, stream) : launch_cfg<256, 128, 4, 2, 3, 8, false>(p, stream);
     return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);
-}
-
-// Split-K factor for a skinny GEMM-shaped conv (the 25088 -> 512 FC: 8 output tiles but 392
-// k-steps): the largest divisor of nk that keeps >= 8 k-steps per slice and does not exceed the
-// CU count in (tile, slice) pairs.  1 = no split.
-int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_cu) {
-    if (!(flags & FRP_FLAG_OUT_F32) || has_res || (Ktot & 63)) return 1;
-    const int nk = Ktot / 64;
-    const long tiles = (long)((M + 255) / 256) * ((Cout + 127) / 128);
-    if (tiles * 4 > n_cu || nk < 64) return 1;
-    int best = 1;
-    for (int s = 2; s <= nk / 8; ++s)
-        if (nk % s == 0 && tiles * s <= n_cu) best = s;
-    return best;
 }
 
 }  // namespace frp

@@ -13,6 +13,9 @@
 #include <vector>
 
 #include "frp.h"
+#ifdef FRP_LAB
+#include "frp_lab.h"
+#endif
 #include "frp_blob.h"
 #include "frp_internal.h"
 
@@ -72,9 +75,12 @@ struct frp_handle {
     int canvas_h = 0, canvas_w = 0;
     // per-call results (device)
     DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws, dense_logits;
-    int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them
+    int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them (-1: factor chosen on the device)
+    int fc_ktot = 0;
     const float* fc_bias = nullptr;
-    int last_B = 0, last_K = 0, last_nfaces = 0;
+    int last_B = 0, last_K = 0, last_nfaces = 0;   // last_nfaces -1: count still on the device (resolve_count)
+    int last_cap = 0, pend_cap = 0;
+    double pend_flops = 0.0, pend_f8flops = 0.0;
     bool ev_pending = false;   // frp_process_resident's stage events are recorded but not yet read (see settle_events)
     bool last_matched = false;
     int32_t* h_nfaces = nullptr;   // pinned
@@ -83,6 +89,7 @@ struct frp_handle {
     // gallery snapshot
     DevBuf gallery;
     int64_t g_rows = 0;
+    DevBuf g_reserved;               // frp_gallery_reserve: filled by the caller, swapped in by frp_gallery_commit
     // profiling
     hipEvent_t ev[EV_COUNT]{};
     frp_counters ctr{};
@@ -248,7 +255,11 @@ bool stem12_fusable(const Net& net) {
     return true;
 }
 
-int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr) {
+// `n_dev`: the number of images that really exist lives in device memory (`batch` is then the capacity the buffers were
+// planned for): every kernel derives its tile count from it.  The flop counters are charged for `batch` images and
+// corrected by the caller once the count is known.
+int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr,
+            const int32_t* n_dev = nullptr) {
     // dims are re-derived while walking (physical buffers are reused by several tensors)
     std::vector<TensorDims> d(net.n_bufs);
     d[net.in_buf] = {H, W, net.in_ch, false};
@@ -289,6 +300,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
             ep.bias = (const float*)(wbase + a.bias_off);
             ep.slope = (const float*)(wbase + a.slope_off);
             ep.out = (_Float16*)net.bufs[a.out_buf].p;
+            ep.n_dev = n_dev;
             hipError_t e = launch_emb_stem(ep, h->stream);
             if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_emb_stem: ") + hipGetErrorString(e));
             d[a.out_buf] = {H, W, 64, false};
@@ -325,6 +337,8 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.out = net.bufs[op.out_buf].p;
         p.N = batch; p.H = in.h; p.W = in.w; p.Cin = op.cin; p.Cout = op.cout;
         p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
+        p.n_dev = n_dev;
+        p.n_cu = h->n_cu;
         p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
         if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
         p.in_scale = p.out_scale = 1.0f;
@@ -342,16 +356,18 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         h->fc_ksplit = 0;
         if ((op.flags & FRP_FLAG_OUT_F32) && &op == &net.ops.back() && !getenv("FRP_NO_SPLITK")) {
             const int ncu = h->n_cu;
-            const int ks = conv_pick_ksplit(batch * ((in.h + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1) *
-                                                ((in.w + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1),
-                                            op.cout, op.ksize * op.ksize * op.cin, op.flags, op.res_buf >= 0, ncu);
+            const int hw_out = ((in.h + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1) * ((in.w + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1);
+            // device-side count: the kernel picks the factor of the real batch itself (the same function), the slabs are
+            // sized for the largest one - that of a single image - times the capacity
+            const int ks = conv_pick_ksplit((n_dev ? 1 : batch) * hw_out, op.cout, op.ksize * op.ksize * op.cin, op.flags, op.res_buf >= 0, ncu);
             if (ks > 1) {
                 const size_t slab = (size_t)ks * batch * op.cout * 4;   // 1x1 output per image for the FC shape
                 if (in.h == 1 && in.w == 1 && ensure(h, h->splitk_ws, slab) == FRP_OK) {
-                    p.ksplit = ks;
+                    p.ksplit = n_dev ? -1 : ks;
                     p.out = h->splitk_ws.p;
-                    h->fc_ksplit = ks;
+                    h->fc_ksplit = p.ksplit;
                     h->fc_bias = p.bias;
+                    h->fc_ktot = op.ksize * op.ksize * op.cin;
                 }
             }
         }
@@ -522,22 +538,23 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
 }
 
 // chips for n faces are in emb.bufs[in]; run embedder + l2norm (+ fp16 copy for the matcher)
-int run_embed(frp_handle* h, int n) {
+int run_embed(frp_handle* h, int n, const int32_t* n_dev = nullptr) {
     if (n <= 0) return FRP_OK;
-    FRPCHK(run_net(h, h->emb, n, FRP_CHIP, FRP_CHIP, &h->ctr.emb_conv_flops, &h->ctr.emb_conv_launches));
+    FRPCHK(run_net(h, h->emb, n, FRP_CHIP, FRP_CHIP, &h->ctr.emb_conv_flops, &h->ctr.emb_conv_launches, nullptr, n_dev));
     rec(h, EV_EMB);
     const int mpad = round_up(n, 32);
     FRPCHK(ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2));
     HIPCHK(h, hipMemsetAsync(h->q16.p, 0, (size_t)mpad * FRP_EMB_DIM * 2, h->stream));
     hipError_t e = launch_l2norm((float*)h->emb.bufs[h->hdr.emb_out_buf].p, (_Float16*)h->q16.p, n, FRP_EMB_DIM, h->stream,
-                                 h->fc_ksplit > 1 ? (const float*)h->splitk_ws.p : nullptr, h->fc_ksplit, h->fc_bias);
+                                 h->fc_ksplit != 0 && h->fc_ksplit != 1 ? (const float*)h->splitk_ws.p : nullptr, h->fc_ksplit, h->fc_bias,
+                                 n_dev, h->fc_ktot, h->n_cu);
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("l2norm: ") + hipGetErrorString(e));
     rec(h, EV_L2);
     return FRP_OK;
 }
 
 // q16 [mpad,512] holds n unit queries -> best_idx/best_cos [n]
-int run_match(frp_handle* h, int n, float* all_scores_dev) {
+int run_match(frp_handle* h, int n, float* all_scores_dev, const int32_t* n_dev = nullptr) {
     if (n <= 0) return FRP_OK;
     if (h->g_rows <= 0) return fail(h, FRP_ERR_NO_GALLERY, "gallery is empty");
     const int mpad = round_up(n, 32);
@@ -555,6 +572,7 @@ int run_match(frp_handle* h, int n, float* all_scores_dev) {
     mp.part_cos = (float*)h->part_cos.p; mp.part_idx = (int32_t*)h->part_idx.p;
     mp.best_cos = (float*)h->best_cos.p; mp.best_idx = (int32_t*)h->best_idx.p;
     mp.all_scores = all_scores_dev;
+    mp.n_dev = n_dev;
     hipError_t e = launch_match(mp, h->stream);
     if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("match: ") + hipGetErrorString(e));
     h->ctr.match_bytes += (double)h->g_rows * FRP_EMB_DIM * 2;
@@ -567,16 +585,30 @@ int run_match(frp_handle* h, int n, float* all_scores_dev) {
 int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
     const int B = h->rB;
     int n;
+    // Threshold mode (the reference's loop, routes/camera.py:232-259): how many faces the detector kept is known on the
+    // device only.  It STAYS there: align, the embedder's kernels, the l2norm and the matcher are launched for the capacity
+    // B x K and read the count from device memory (grids sized for the capacity; workgroups beyond the real tiles leave at
+    // once), so the pipeline has no host round trip.  The host learns the count with the results (frp_fetch_results).
+    // FRP_HOST_COUNT=1 keeps the former path (copy the count, wait, launch for exactly n) for A/B runs - both give the
+    // same bits.  More than FRP_MATCH_TOP1_MAX slots: the per-tile matcher has no device-count form, former path.
+    const bool dev_count = n_known < 0 && round_up(B * K, 32) <= FRP_MATCH_TOP1_MAX && !getenv("FRP_HOST_COUNT");
+    const int32_t* n_dev = nullptr;
     if (n_known >= 0) {
         n = n_known;
+    } else if (dev_count) {
+        n = B * K;
+        n_dev = (const int32_t*)h->nfaces.p;
+        HIPCHK(h, hipMemcpyAsync(h->h_nfaces, h->nfaces.p, 4, hipMemcpyDeviceToHost, h->stream));   // read after the next wait
     } else {
         HIPCHK(h, hipMemcpyAsync(h->h_nfaces, h->nfaces.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         n = *h->h_nfaces;
         if (n < 0 || n > B * K) return fail(h, FRP_ERR_HIP, "corrupt face count");
     }
-    h->last_nfaces = n;
+    h->last_nfaces = n_dev ? -1 : n;          // -1: pending, resolved by the next call that waits for the stream
+    h->last_cap = n;
     h->last_matched = false;
+    const double flops0 = h->ctr.emb_conv_flops, f8flops0 = h->ctr.f8_conv_flops;
     if (n > 0) {
         FRPCHK(plan_net(h, h->emb, n, FRP_CHIP, FRP_CHIP));
         AlignParams ap{};
@@ -589,14 +621,15 @@ int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
         ap.max_faces = K;
         ap.face_slot = (const int32_t*)h->face_slot.p;
         ap.n_faces = n;
+        ap.n_dev = n_dev;
         ap.rgb_in = (flags & FRP_FLAG_RGB) ? 1 : 0;
         ap.chips = (_Float16*)h->emb.bufs[h->emb.in_buf].p;
         hipError_t e = launch_align(ap, h->stream);
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("align: ") + hipGetErrorString(e));
         rec(h, EV_ALIGN);
-        FRPCHK(run_embed(h, n));
+        FRPCHK(run_embed(h, n, n_dev));
         if (!(flags & FRP_FLAG_NO_MATCH) && h->g_rows > 0) {
-            FRPCHK(run_match(h, n, nullptr));
+            FRPCHK(run_match(h, n, nullptr, n_dev));
             h->last_matched = true;
         }
         rec(h, EV_MATCH);
@@ -604,8 +637,27 @@ int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
         rec(h, EV_ALIGN); rec(h, EV_EMB); rec(h, EV_L2); rec(h, EV_MATCH);
     }
     h->ctr.frames += B;
-    h->ctr.faces += n;
+    if (n_dev) {
+        h->pend_flops = h->ctr.emb_conv_flops - flops0;      // charged for the capacity: corrected once the count is known
+        h->pend_f8flops = h->ctr.f8_conv_flops - f8flops0;
+        h->pend_cap = n;
+    } else {
+        h->ctr.faces += n;
+    }
     return FRP_OK;
+}
+
+// the face count of a device-count pass, once the stream has been waited for (h_nfaces was copied behind the pass)
+void resolve_count(frp_handle* h) {
+    if (h->last_nfaces >= 0) return;
+    int n = *h->h_nfaces;
+    if (n < 0 || n > h->last_cap) n = 0;
+    h->last_nfaces = n;
+    h->ctr.faces += n;
+    if (h->pend_cap > 0) {
+        h->ctr.emb_conv_flops += h->pend_flops * n / h->pend_cap - h->pend_flops;
+        h->ctr.f8_conv_flops += h->pend_f8flops * n / h->pend_cap - h->pend_f8flops;
+    }
 }
 
 int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
@@ -682,8 +734,13 @@ int ensure_pinned(frp_handle* h, size_t bytes) {
 
 int fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_t* counts, float* emb,
                   int32_t* match_idx, float* match_cos) {
-    const int B = h->last_B, K = h->last_K, n = h->last_nfaces;
+    const int B = h->last_B, K = h->last_K;
     if (B <= 0) return fail(h, FRP_ERR_INVALID, "nothing to fetch");
+    if (h->last_nfaces < 0) {                  // device-count pass: one short wait for the count, then copy exactly n rows
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        resolve_count(h);
+    }
+    const int n = h->last_nfaces;
     const size_t s = (size_t)B * K;
     const bool want_emb = n > 0 && emb, want_match = n > 0 && h->last_matched && (match_idx || match_cos);
     // staging layout: counts | boxes | kps | scores | emb (compact, n rows) | idx | cos
@@ -830,7 +887,8 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
-                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery};
+                     &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery,
+                     &h->g_reserved};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
@@ -934,6 +992,35 @@ int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_
     h->gallery = fresh;
     h->g_rows = n;
     return FRP_OK;
+}
+
+int frp_gallery_reserve(frp_handle* h, int64_t capacity_rows, void** dev_f16) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!dev_f16 || capacity_rows <= 0 || capacity_rows > 0x7fffff00L) return fail(h, FRP_ERR_INVALID, "bad gallery reservation");
+    release(h->g_reserved);
+    FRPCHK(ensure(h, h->g_reserved, (size_t)capacity_rows * FRP_EMB_DIM * 2));
+    *dev_f16 = h->g_reserved.p;
+    return FRP_OK;
+}
+
+int frp_gallery_commit(frp_handle* h, int64_t n_rows) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->g_reserved.p || n_rows < 0 || (size_t)n_rows * FRP_EMB_DIM * 2 > h->g_reserved.cap)
+        return fail(h, FRP_ERR_INVALID, "gallery commit without a matching reservation");
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // nothing of this handle still reads the old snapshot
+    release(h->gallery);
+    h->gallery = h->g_reserved;
+    h->g_reserved = DevBuf();
+    h->g_rows = n_rows;
+    return FRP_OK;
+}
+
+const void* frp_gallery_device_ptr(frp_handle* h) {
+    if (!h) return nullptr;
+    Guard g(h);
+    return h->g_rows > 0 ? h->gallery.p : nullptr;
 }
 
 int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype) {
@@ -1072,6 +1159,7 @@ int frp_synchronize(frp_handle* h) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h, false);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    resolve_count(h);
     settle_events(h, true);
     return FRP_OK;
 }
@@ -1490,6 +1578,7 @@ int frp_conv2d_f8(frp_handle* h, const void* x8, int32_t N, int32_t H, int32_t W
     return FRP_OK;
 }
 
+#ifdef FRP_LAB   // tuning hooks (include/frp_lab.h): only in libfrp_lab.so
 int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
                    int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg, uint64_t* stamps_out) {
     if (!h) return FRP_ERR_INVALID;
@@ -1617,6 +1706,8 @@ int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops) 
                       (ms * 1e-3) / 1e12);
     return FRP_OK;
 }
+
+#endif  // FRP_LAB
 
 int frp_get_counters(frp_handle* h, frp_counters* out) {
     if (!h || !out) return FRP_ERR_INVALID;

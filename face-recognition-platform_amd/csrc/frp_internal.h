@@ -33,7 +33,11 @@ struct ConvParams {
     int N, H, W, Cin, Cout, KS, stride;
     int act, flags;
     int Hr, Wr;             // residual spatial dims (RES_UP2)
-    int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums
+    int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums;
+                            // -1 (only with n_dev): the kernel picks conv_pick_ksplit(M) itself
+    const int32_t* n_dev;   // null, or the number of images that really exist (<= N) in device memory: the kernel derives
+                            // M and its tile count from it (threshold mode: the face count never visits the host mid-pipeline)
+    int n_cu;               // compute units (input of the device-side split-K choice)
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
     int dbg;                // A/B switch (tests, conv_bench): 1 = generic kernel also for row-patch shapes
     // derived by launch_conv():
@@ -45,7 +49,9 @@ hipError_t launch_conv(const ConvParams& p, hipStream_t stream);
 // row-patch variant for 3x3 stride-1 layers with Cin % 64 == 0 (conv3x3_rows.hip); launch_conv()
 // routes eligible shapes to it.  `p` must carry launch_conv()'s derived fields.
 bool conv3x3_rows_eligible(const ConvParams& p);
-hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);
+#ifdef FRP_LAB
+hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);   // first generation + ablations (lab build only)
+#endif
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // static k-loop generation (conv3x3_lean.hip)
 
 // K1: u8 BGR frames -> normalised fp16 NHWC8 canvas (top-left letterbox, zero u8 pad)
@@ -91,6 +97,7 @@ struct EmbStemParams {
     const float* bias;       // [64]
     const float* slope;      // [64]
     _Float16* out;           // [M,H,W,64]
+    const int32_t* n_dev;    // null, or the number of chips that really exist (<= M), read on the device
 };
 hipError_t launch_emb_stem(const EmbStemParams& p, hipStream_t stream);
 
@@ -124,6 +131,7 @@ struct AlignParams {
     int n_faces;
     int rgb_in;             // frames are RGB instead of BGR
     _Float16* chips;        // [n_faces,112,112,8]
+    const int32_t* n_dev;   // null, or the real face count (<= n_faces, which then is the capacity), read on the device
 };
 hipError_t launch_align(const AlignParams& p, hipStream_t stream);
 // raw aligned u8 chips (BGR [M,112,112,3]) -> normalised fp16 NHWC8
@@ -134,13 +142,28 @@ hipError_t launch_compact_faces(const int32_t* counts, int B, int max_faces, int
 
 // K5 tail: row-wise L2 normalisation of [M,512] fp32 (in place) + fp16 copy for the matcher.
 // With `partials` (split-K FC): emb[m][c] = sum_s partials[s][m][c] + bias[c] first.
+// `n_dev` (optional): the real row count lives in device memory (M is then the capacity); with ksplit == -1 the split
+// factor of the FC that wrote `partials` is re-derived from it (conv_pick_ksplit with fc_ktot, n_cu).
 hipError_t launch_l2norm(float* emb, _Float16* emb16, int M, int D, hipStream_t stream,
-                         const float* partials = nullptr, int ksplit = 0, const float* bias = nullptr);
-// choose a split factor for a conv (1 = none): small M, long K, fp32 output
-int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_cu);
+                         const float* partials = nullptr, int ksplit = 0, const float* bias = nullptr,
+                         const int32_t* n_dev = nullptr, int fc_ktot = 0, int n_cu = 0);
+// Split-K factor for a skinny GEMM-shaped conv (the 25088 -> 512 FC: 8 output tiles but 392 k-steps): the largest divisor
+// of nk that keeps >= 8 k-steps per slice and does not exceed the CU count in (tile, slice) pairs.  1 = no split.
+// Host and device evaluate the same function (device: when the image count is only known there).
+__host__ __device__ inline int conv_pick_ksplit(int M, int Cout, int Ktot, int flags, bool has_res, int n_cu) {
+    if (!(flags & FRP_FLAG_OUT_F32) || has_res || (Ktot & 63) || M <= 0) return 1;
+    const int nk = Ktot / 64;
+    const long tiles = (long)((M + 255) / 256) * ((Cout + 127) / 128);
+    if (tiles * 4 > n_cu || nk < 64) return 1;
+    int best = 1;
+    for (int s = 2; s <= nk / 8; ++s)
+        if (nk % s == 0 && tiles * s <= n_cu) best = s;
+    return best;
+}
 // gallery upload: fp32 rows -> unit fp16 rows
 hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
 
+#ifdef FRP_LAB
 hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream);
 // the conv k-step's MFMA + ds_read_b128 mix without memory traffic or barriers (reads per 4 MFMAs: 4, 3 or 2)
 hipError_t launch_mfma_lds(const _Float16* src, float* dst, int blocks, int reads, int iters, hipStream_t stream);
@@ -149,6 +172,7 @@ hipError_t launch_kstep_lab(const _Float16* src, float* dst, int blocks, int var
 int kstep_lab_steps_per_iter(int variant);
 int kstep_lab_waves(int variant);
 hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scale, hipStream_t stream);
+#endif
 
 // K6: cosine match, top-1 (and optional full score matrix)
 struct MatchParams {
@@ -162,8 +186,10 @@ struct MatchParams {
     int32_t* best_idx;        // [M]
     float* all_scores;        // [M, N] or null
     int n_wg;
+    const int32_t* n_dev;     // null, or the real query count (<= M) in device memory (top-1 path only)
 };
 int match_num_workgroups(long N);
+#define FRP_MATCH_TOP1_MAX 512   // queries per launch the persistent top-1 kernel covers (the only one that takes n_dev)
 hipError_t launch_match(const MatchParams& p, hipStream_t stream);
 // top-k of each row of a device score matrix [M x N] by (cosine desc, row asc); -1 / -2.0 beyond N entries
 hipError_t launch_topk_rows(const float* scores, int M, long N, int k, int32_t* idx_out, float* cos_out, hipStream_t stream);

@@ -146,13 +146,19 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchParams p) {
 // row asc) - the same total order as the first kernel and the oracle, and bit-identical results.
 #define MT_MAXQT 16
 #define MT_NW 8            // waves per workgroup: one query tile in LDS serves 256 gallery rows
+static_assert(MT_MAXQT * MT_Q == FRP_MATCH_TOP1_MAX, "frp_internal.h: FRP_MATCH_TOP1_MAX");
 __global__ __launch_bounds__(64 * MT_NW, 2) void match_top1_kernel(MatchParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char qs0[MT_Q * 1024];
     __shared__ __attribute__((aligned(16))) unsigned char qs1[MT_Q * 1024];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    const int nqt = p.Mpad / MT_Q;                                  // <= MT_MAXQT (launch_match)
+    int nqt = p.Mpad / MT_Q;                                        // <= MT_MAXQT (launch_match)
+    if (p.n_dev) {                                                  // query count known on the device only: tiles that hold
+        int n = *p.n_dev;                                           // real queries (p.M / p.Mpad are the capacity and the stride)
+        n = n < 0 ? 0 : (n > p.M ? p.M : n);
+        nqt = (n + MT_Q - 1) / MT_Q;
+    }
     const long nb = (p.N + 31) / 32;                                // 32-row gallery blocks
     const long wstride = (long)gridDim.x * MT_NW;
     const long rounds = (nb + wstride - 1) / wstride;               // the same for every wave: they share the barriers
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64 * MT_NW, 2) void match_top1_kernel(MatchParams p
 __global__ __launch_bounds__(256) void match_reduce_kernel(MatchParams p) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (q >= p.M) return;
+    if (q >= p.M || (p.n_dev && q >= *p.n_dev)) return;
     float best = -3.0f;
     int bidx = 0x7fffffff;
     for (int w = lane; w < p.n_wg; w += 64) {
@@ -307,6 +313,7 @@ hipError_t launch_match(const MatchParams& p, hipStream_t stream) {
         return hipErrorInvalidValue;
     MatchParams r = p;
     int dev = 0;
+    if (p.n_dev && (p.all_scores || p.Mpad > MT_MAXQT * MT_Q || getenv("FRP_MATCH_V1"))) return hipErrorInvalidValue;   // top-1 kernel only
     if (!p.all_scores && p.Mpad <= MT_MAXQT * MT_Q && !getenv("FRP_MATCH_V1") && hipGetDevice(&dev) == hipSuccess) {
         // top-1 for a streaming batch: persistent workgroups, running winners in registers; its partials are the first
         // `grid` rows of the buffers the caller sized for the per-tile kernel (grid <= n_wg)

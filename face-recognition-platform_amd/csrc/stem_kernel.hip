@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void emb_stem_kernel(EmbStemParams p) {
     const int tx = q % tiles_x; q /= tiles_x;
     const int ty = q % tiles_y;
     const int img = q / tiles_y;
+    if (p.n_dev && img >= *p.n_dev) return;                                // chips beyond the device-side count do not exist
     const int y0 = ty * ES_ROWS, x0 = tx * ES_COLS;
     const _Float16* chip = p.x + (long)img * p.H * p.W * 8;
 

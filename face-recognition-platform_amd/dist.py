@@ -10,10 +10,12 @@ import numpy as np
 
 
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
-    """rows [first, first+count) owned by `rank`: contiguous, sizes differ by at most 1."""
-    base, rem = divmod(n_total, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+    """rows [first, first+count) owned by `rank`: contiguous blocks of ceil(N / R) rows, the last ranks take what is left
+    (possibly nothing).  Equal block offsets are what lets the all-gather land every shard at its final position of the
+    full matrix - no padding between shards, no compaction copy afterwards."""
+    block = (n_total + world - 1) // world if world > 0 else 0
+    first = min(rank * block, n_total)
+    return first, min(block, n_total - first)
 
 
 def stream_to_rank(stream_id: int, world: int) -> int:
@@ -32,46 +34,61 @@ def normalize_rows_f16(rows: np.ndarray) -> np.ndarray:
     return (r / n).astype(np.float16)
 
 
-def allgather_gallery(shard_f16, n_total: int, device=None):
-    """All-gather unit fp16 shards [count_r, 512] (ragged by <=1 row) into the full
-    [n_total, 512] tensor on every rank.  torch.distributed must be initialised
-    (backend nccl == RCCL on GPUs, gloo on CPU)."""
+class _DevicePtr:
+    """a raw device allocation as something torch.as_tensor accepts (__cuda_array_interface__, version 2)"""
+
+    def __init__(self, ptr: int, rows: int, cols: int):
+        self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f2", "data": (ptr, False), "version": 2, "strides": None}
+
+
+def allgather_gallery(shard_f16, n_total: int, device=None, out=None):
+    """All-gather unit fp16 shards (rank r holds rows shard_range(n_total, r, R)) into the full matrix on every rank.
+    `out`: a [R * ceil(N/R), 512] fp16 tensor to gather INTO (the engine's reserved snapshot); allocated when None.
+    Every shard lands at its final row offset r * ceil(N/R), so rows [0, n_total) of `out` ARE the gallery: the only
+    staging is this rank's own shard padded to the block size.  torch.distributed must be initialised (backend nccl ==
+    RCCL on GPUs, gloo on CPU).  -> out[:n_total] (a view)"""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    max_rows = (n_total + world - 1) // world
+    block = (n_total + world - 1) // world
     t = torch.as_tensor(shard_f16)
     if device is not None:
         t = t.to(device)
-    pad = torch.zeros((max_rows, t.shape[1]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
-    out = torch.empty((world * max_rows, t.shape[1]), dtype=t.dtype, device=t.device)
+    if t.shape[0] != block:                                  # the last ranks' short (or empty) shards
+        pad = torch.zeros((block, t.shape[1]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        t = pad
+    if out is None:
+        out = torch.empty((world * block, t.shape[1]), dtype=t.dtype, device=t.device)
+    if out.shape[0] != world * block or out.dtype != t.dtype or not out.is_contiguous():
+        raise ValueError("all-gather target must be a contiguous [R * ceil(N/R), 512] fp16 tensor")
     if dist.get_backend() == "gloo":
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        out = torch.cat(parts, 0)
+        dist.all_gather(list(out.chunk(world, 0)), t.contiguous())       # chunks are row-block views of `out`
     else:
-        dist.all_gather_into_tensor(out, pad)
-    # drop the per-rank padding
-    keep = []
-    for r in range(world):
-        _, cnt = shard_range(n_total, r, world)
-        keep.append(out[r * max_rows: r * max_rows + cnt])
-    return torch.cat(keep, 0).contiguous()
+        dist.all_gather_into_tensor(out, t.contiguous())
+    return out[:n_total]
 
 
 def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int, int], np.ndarray], local_rank: int):
-    """Rank r builds rows [first, first+count) on the host, uploads them as unit fp16,
-    all-gathers over RCCL and hands the device matrix to the engine (frp_gallery_set_device)."""
+    """Rank r builds rows shard_range(n_total, r, R) on the host, uploads them as unit fp16 and all-gathers over RCCL
+    STRAIGHT INTO the snapshot the first engine reserved (frp_gallery_reserve / frp_gallery_commit): the matrix exists
+    once per handle, not three more times in torch tensors.  Further lanes of this GPU copy theirs from the first."""
     import torch
     import torch.distributed as dist
-    first, cnt = shard_range(n_total, dist.get_rank(), dist.get_world_size())
-    shard = normalize_rows_f16(make_rows(first, cnt))
-    full = allgather_gallery(shard, n_total, device=torch.device("cuda", local_rank))
+    engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+    world = dist.get_world_size()
+    first, cnt = shard_range(n_total, dist.get_rank(), world)
+    shard = normalize_rows_f16(make_rows(first, cnt)) if cnt else np.zeros((0, 512), np.float16)
+    block = (n_total + world - 1) // world
+    dev = torch.device("cuda", local_rank)
+    ptr = engines[0].gallery_reserve(world * block)
+    out = torch.as_tensor(_DevicePtr(ptr, world * block, 512), device=dev)
+    allgather_gallery(shard, n_total, device=dev, out=out)
     torch.cuda.synchronize()
-    for e in (engine if isinstance(engine, (list, tuple)) else [engine]):     # every lane of this GPU gets its own copy
-        e.gallery_set_device(full.data_ptr(), n_total)
-    return full.shape[0]
+    engines[0].gallery_commit(n_total)
+    for e in engines[1:]:                                    # every lane of this GPU matches against its own copy
+        e.gallery_set_device(engines[0].gallery_device_ptr(), n_total)
+    return n_total
 
 
 def broadcast_names(names: Sequence[str], src: int = 0) -> List[str]:
@@ -80,3 +97,58 @@ def broadcast_names(names: Sequence[str], src: int = 0) -> List[str]:
     box = [list(names) if dist.get_rank() == src else None]
     dist.broadcast_object_list(box, src=src)
     return box[0]
+
+
+class GalleryReplicator:
+    """Enrolment and deletion at run time on a multi-GPU node (reference: ENCODINGS[name] = ... / del ENCODINGS[name] on the
+    one process it has, backend/app/services/face_service.py:374,522).  Every rank holds the whole watch list; an update
+    made on one rank must reach all of them, and in the SAME ORDER everywhere, so that every rank's device matrix, row
+    numbering and name table stay identical (swap-remove makes the layout order-dependent).
+
+    `store` / `delete` only queue the update on the calling rank.  `sync()` is a collective every rank calls at the same
+    point of its loop (once per batch or per poll): the queued updates of all ranks are exchanged (all_gather_object: a
+    name, an op code and the 512 fp32 values per update - a few KB, off the frame path) and applied in (rank, queue
+    order) on every rank through `Gallery.put / remove`, i.e. under the gallery's exclusive lock and into every lane's
+    copy.  An update is therefore visible one sync later - on all ranks at once.  `generation` counts applied rounds that
+    carried at least one update and is identical on every rank."""
+
+    def __init__(self, gallery, group=None):
+        import threading
+        self.gallery = gallery
+        self.group = group
+        self._lock = threading.Lock()
+        self._pending: List[tuple] = []
+        self.generation = 0
+        self.applied = 0
+
+    def store(self, name: str, emb) -> None:
+        e = np.asarray(emb, dtype=np.float32).reshape(-1)
+        if e.shape[0] != 512:
+            raise ValueError("embedding must have 512 values")
+        with self._lock:
+            self._pending.append(("put", str(name), e.tobytes()))
+
+    def delete(self, name: str) -> None:
+        with self._lock:
+            self._pending.append(("del", str(name), b""))
+
+    def sync(self) -> int:
+        """collective: exchange and apply the queued updates of every rank.  -> number of updates applied (all ranks)"""
+        import torch.distributed as dist
+        with self._lock:
+            mine, self._pending = self._pending, []
+        world = dist.get_world_size(self.group)
+        box = [None] * world
+        dist.all_gather_object(box, mine, group=self.group)
+        n = 0
+        for r in range(world):
+            for op, name, payload in box[r]:
+                if op == "put":
+                    self.gallery.put(name, np.frombuffer(payload, dtype=np.float32))
+                else:
+                    self.gallery.remove(name)
+                n += 1
+        if n:
+            self.generation += 1
+            self.applied += n
+        return n

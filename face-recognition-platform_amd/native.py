@@ -29,12 +29,12 @@ F32, F16, F64 = 0, 1, 2
 
 ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
-    "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_update_row", "frp_gallery_remove_row",
+    "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
     "frp_gallery_size", "frp_gallery_get",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
-    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv2d_f8", "frp_conv_bench", "frp_mfma_peak", "frp_kstep_lab", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
+    "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv2d_f8", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
 ]
 
 
@@ -99,6 +99,10 @@ def load_library() -> C.CDLL:
     lib.frp_load_weights.argtypes = [vp, vp, C.c_size_t]
     lib.frp_gallery_set.argtypes = [vp, vp, i64, i32, i32]
     lib.frp_gallery_set_device.argtypes = [vp, vp, i64, i32]
+    lib.frp_gallery_reserve.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
+    lib.frp_gallery_commit.argtypes = [vp, i64]
+    lib.frp_gallery_device_ptr.argtypes = [vp]
+    lib.frp_gallery_device_ptr.restype = vp
     lib.frp_gallery_update_row.argtypes = [vp, i64, vp, i32, i32]
     lib.frp_gallery_remove_row.argtypes = [vp, i64]
     lib.frp_gallery_size.argtypes = [vp]
@@ -128,9 +132,10 @@ def load_library() -> C.CDLL:
     lib.frp_match_scores.argtypes = [vp, vp, i32, vp, i64]
     lib.frp_conv2d_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.frp_conv2d_f8.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]
-    lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
-    lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
-    lib.frp_kstep_lab.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    if hasattr(lib, "frp_kstep_lab"):            # the FRP_LAB build (libfrp_lab.so, include/frp_lab.h): tuning hooks
+        lib.frp_conv_bench.argtypes = [vp] + [i32] * 11 + [C.POINTER(C.c_float), vp]
+        lib.frp_mfma_peak.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+        lib.frp_kstep_lab.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.frp_get_counters.argtypes = [vp, C.POINTER(FrpCounters)]
     lib.frp_reset_counters.argtypes = [vp]
     lib.frp_set_profile.argtypes = [vp, i32]
@@ -200,6 +205,19 @@ class Engine:
 
     def gallery_set_device(self, dev_ptr: int, n: int):
         self._chk(self._lib.frp_gallery_set_device(self._h, C.c_void_p(dev_ptr), n, EMB_DIM))
+
+    def gallery_reserve(self, capacity_rows: int) -> int:
+        """device address of a fresh, not yet visible snapshot of capacity_rows x 512 fp16 (fill it, then gallery_commit)"""
+        ptr = C.c_void_p()
+        self._chk(self._lib.frp_gallery_reserve(self._h, capacity_rows, C.byref(ptr)))
+        return int(ptr.value)
+
+    def gallery_commit(self, n_rows: int):
+        self._chk(self._lib.frp_gallery_commit(self._h, n_rows))
+
+    def gallery_device_ptr(self) -> int:
+        """device address of the current snapshot (0 when empty); valid until the next gallery update"""
+        return int(self._lib.frp_gallery_device_ptr(self._h) or 0)
 
     def gallery_update_row(self, row: int, emb: np.ndarray):
         e = np.ascontiguousarray(emb, dtype=np.float32).reshape(-1)
@@ -448,7 +466,14 @@ class Engine:
                                           _ptr(res), act, flags | (64 if out_fp8 else 0), in_scale, out_scale, _ptr(out), _ptr(out2)))
         return (out, out2) if copy_fp8 else out
 
+    def _lab(self, name: str):
+        if not hasattr(self._lib, name):
+            raise RuntimeError(f"{name} lives in the lab build only: `make -C face-recognition-platform_amd/csrc lab` and run with "
+                               "FRP_LIB=face-recognition-platform_amd/libfrp_lab.so (tools/ do that through tools/_lab.py)")
+        return getattr(self._lib, name)
+
     def conv_bench(self, N, H, W, Cin, Cout, k=3, stride=1, act=0, flags=0, with_res=False, iters=20, stamps=False):
+        self._lab("frp_conv_bench")
         ms = C.c_float()
         st = np.zeros((256, 8), np.uint64) if stamps else None
         self._chk(self._lib.frp_conv_bench(self._h, N, H, W, Cin, Cout, k, stride, act, flags, int(with_res), iters, C.byref(ms), _ptr(st)))
@@ -456,6 +481,7 @@ class Engine:
 
     def mfma_peak(self, waves_per_simd=1, iters=20000) -> float:
         t = C.c_float()
+        self._lab("frp_mfma_peak")
         self._chk(self._lib.frp_mfma_peak(self._h, waves_per_simd, iters, C.byref(t)))
         return float(t.value)
 
@@ -467,6 +493,7 @@ class Engine:
     def kstep_lab(self, variant: int, iters: int = 3000) -> float:
         """TFLOP/s of the conv k-step's inner loop in isolation under schedule `variant` (csrc/kstep_lab.hip)"""
         t = C.c_float()
+        self._lab("frp_kstep_lab")
         self._chk(self._lib.frp_kstep_lab(self._h, int(variant), int(iters), C.byref(t)))
         return float(t.value)
 

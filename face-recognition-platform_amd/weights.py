@@ -412,8 +412,8 @@ def pack_blob(raw: Dict[str, np.ndarray], det_blocks=(1, 2, 2, 2), emb_blocks=(3
                 flags |= OPFLAG_FP8_MFMA
             if pl["out8"]:
                 flags |= OPFLAG_OUT_FP8
-            if weight_format in ("fp8", "fp8-mfma"):
-                codes, scale = fp8_quantize_rows(w16)
+            if weight_format == "fp8" or (weight_format == "fp8-mfma" and fp8_mfma):      # fp8-mfma: "fp8 ArcFace weights" - the
+                codes, scale = fp8_quantize_rows(w16)                                     # detector keeps its fp16 weights
                 w_off = put(codes)
                 data.extend(b"\0" * ((-len(data)) % 16))
                 data.extend(scale.astype("<f4").tobytes())

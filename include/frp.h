@@ -106,6 +106,16 @@ int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_
 /* rows already unit-norm fp16 in device memory of this handle's GPU (e.g. the output
  * of an RCCL all-gather); copied into a library-owned snapshot */
 int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_t d);
+/* Zero-copy import of a matrix produced ON this GPU (the RCCL all-gather of the watch-list shards):
+ * frp_gallery_reserve allocates a fresh, not yet visible snapshot of `capacity_rows` x 512 fp16 and returns its device
+ * address; the caller (a collective, a kernel) fills rows [0, n) with UNIT fp16 rows and finishes its stream work;
+ * frp_gallery_commit(n) makes it the gallery (n <= capacity; the old snapshot is released).  A second reserve, or any
+ * other gallery call in between, discards the reservation. */
+int frp_gallery_reserve(frp_handle* h, int64_t capacity_rows, void** dev_f16);
+int frp_gallery_commit(frp_handle* h, int64_t n_rows);
+/* device address of the current snapshot (rows [0, frp_gallery_size)), valid until the next gallery update on this handle:
+ * the source from which a second handle on the same GPU copies its own snapshot (frp_gallery_set_device) */
+const void* frp_gallery_device_ptr(frp_handle* h);
 int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype); /* row == size appends */
 int frp_gallery_remove_row(frp_handle* h, int64_t row); /* last row moves into `row` (store/delete: face_service.py:374,522) */
 int64_t frp_gallery_size(const frp_handle* h);
@@ -209,19 +219,6 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
 int frp_conv2d_f8(frp_handle* h, const void* x8, int32_t N, int32_t H, int32_t W, int32_t Cin, const void* w8, int32_t Cout,
                   const float* wscale, const float* bias, const float* slope, const void* res16, int32_t act, int32_t flags,
                   float in_scale, float out_scale, void* out, void* out2_f8);
-
-/* tuning hook: average milliseconds of `iters` back-to-back launches of one conv shape on
- * random device-resident operands (HIP events on the handle's stream) */
-int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
-                   int32_t act, int32_t flags, int32_t with_res, int32_t iters, float* ms_avg,
-                   uint64_t* stamps_out /* NULL, or [256][8] per-workgroup 100 MHz phase stamps of the last launch */);
-
-/* tuning hook: sustained v_mfma_f32_32x32x16_f16 rate of this device on register operands (waves_per_simd 1..8),
- * or - waves_per_simd = 16*r + 2, r in {4,3,2} - of the conv k-step's mix: 8 waves per CU, r ds_read_b128 per 4 MFMAs */
-int frp_mfma_peak(frp_handle* h, int32_t waves_per_simd, int32_t iters, float* tflops);
-
-/* tuning hook: the conv k-step's inner loop in isolation under different schedules (csrc/kstep_lab.hip) */
-int frp_kstep_lab(frp_handle* h, int32_t variant, int32_t iters, float* tflops);
 
 /* ---- observability ---------------------------------------------------------------
  * replaces: FaceService._metrics / get_performance_metrics (face_service.py:69-77,636-656) */

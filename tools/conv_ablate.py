@@ -5,6 +5,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (selects libfrp_lab.so)
 import frp_amd_loader  # noqa: E402,F401
 from frp_amd import native  # noqa: E402
 

@@ -2,6 +2,8 @@
 """Run ONE conv shape a few times (for rocprofv3 --pmc runs). args: N H W Cin Cout k stride iters"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (selects libfrp_lab.so)
 import frp_amd_loader  # noqa
 from frp_amd import native
 a = [int(x) for x in sys.argv[1:9]]

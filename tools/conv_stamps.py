@@ -3,6 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (selects libfrp_lab.so)
 import frp_amd_loader  # noqa
 from frp_amd import native
 a = [int(x) for x in sys.argv[1:8]] if len(sys.argv) > 7 else [320, 14, 14, 256, 256, 3, 1]

@@ -2,6 +2,8 @@
 """64-cout 3x3 layers: 512 x 64 tile (two-slot patch ring) vs the 256 x 64 tile (dbg bit 128), per-launch time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (selects libfrp_lab.so)
 import frp_amd_loader  # noqa
 from frp_amd import native
 eng = native.Engine(0)
