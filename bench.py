@@ -305,10 +305,15 @@ def main():
         del g_
     assert all(e_.gallery_size() == N for e_ in lanes)
 
-    if args.workload == "config5":     # two camera streams per GPU, interleaved frame by frame into the batch
-        two = [synth_frames(B // 2, H, W, K, 1234 + 2 * rank + s_) for s_ in range(2)]
-        frames = np.empty((B, H, W, 3), np.uint8)
-        frames[0::2], frames[1::2] = two[0], two[1]
+    if args.workload == "config5":     # 16 synthetic streams over 8 GPUs: this rank's two (stream s -> rank s mod R), mixed
+        from frp_amd import dist as fdist_, mixer as mx          # frame by frame into one batch by the stream mixer
+        my_streams = fdist_.streams_of_rank(2 * max(1, world), rank, max(1, world))
+        caps = {s_: mx.SyntheticStream(synth_frames(B // 2, H, W, K, 1234 + s_)) for s_ in my_streams}
+        mixer_ = mx.StreamMixer(caps, batch=B, buffers=[eng.host_frames(B, H, W)])
+        frames, meta_ = next(iter(mixer_))
+        mixer_.close()
+        assert [m_[0] for m_ in meta_] == [my_streams[i_ % 2] for i_ in range(B)]
+        frames = frames.copy()
     else:
         frames = synth_frames(B, H, W, K, 1234 + rank)
     flags = native.FLAG_FORCED_K
@@ -475,8 +480,8 @@ def main():
                      "mode": f"{L} lanes, resident frames, score threshold + NMS + ragged face counts, host results out every step"}
         for e_ in lanes:
             e_.upload_frames(frames)
-    # The boundary the reference's callers use (never `value`): FaceService.process_stream from HOST frames (pageable memory,
-    # the blocking frp_process_frames call per batch) to the per-frame lists of per-face dicts the route hands on
+    # The boundary the reference's callers use (never `value`): FaceService.process_stream from HOST frames (page-locked
+    # capture buffers, the blocking frp_process_frames call per batch) to the per-frame lists of per-face dicts the route hands on
     # (routes/camera.py:243-259) - name lookup, distance, bucket and threshold included - on the same two lanes, in
     # threshold mode (the service API has no forced-K switch).  Compare with threshold_mode_lanes (engine level, resident).
     svc_line = None
@@ -485,11 +490,15 @@ def main():
         n_s = args.steps if args.threshold_steps < 0 else args.threshold_steps
         svc = FaceService(engine=lanes[0], second_engine=lanes[1])
         svc.ENCODINGS.adopt_device([f"id{i:07d}" for i in range(N)])
-        for _ in svc.process_stream((frames for _ in range(2)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
+        # capture buffers: page-locked (FaceService.frame_buffer), four in rotation as a capture thread would fill them
+        bufs = [svc.frame_buffer(B, H, W) for _ in range(4)]
+        for b_ in bufs:
+            b_[...] = frames
+        for _ in svc.process_stream((bufs[i_ % 4] for i_ in range(2)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
             pass
         t_v = time.perf_counter()
         n_faces_v = n_match_v = 0
-        for per_frame in svc.process_stream((frames for _ in range(n_s)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
+        for per_frame in svc.process_stream((bufs[i_ % 4] for i_ in range(n_s)), max_faces=K, det_thresh=thr_lanes["det_thresh"]):
             for faces in per_frame:
                 n_faces_v += len(faces)
                 n_match_v += sum(1 for f_ in faces if f_["target"] is not None)
@@ -498,7 +507,7 @@ def main():
         svc_line = {"faces_per_s": round(n_faces_v / dt_v, 1), "frames_per_s": round(n_s * B / dt_v, 1),
                     "ms_per_step": round(dt_v / n_s * 1e3, 3), "steps": n_s,
                     "fraction_of_engine_threshold_mode_lanes": round((n_faces_v / dt_v) / max(1e-9, thr_lanes["faces_per_s"]), 3),
-                    "mode": "FaceService.process_stream: pageable host frames in (blocking upload per batch), list of per-face dicts out "
+                    "mode": "FaceService.process_stream: host frames in page-locked capture buffers (FaceService.frame_buffer; upload per batch on the lane's stream), list of per-face dicts out "
                             "(target name, distance, cosine, confidence bucket, match flag, bbox, kps, score, 512-d embedding), 2 lanes, threshold mode"}
         for e_ in lanes:
             e_.upload_frames(frames)

@@ -1,0 +1,420 @@
+// K2c: 3x3 stride-1 convolution as Winograd F(2,3) ALONG THE IMAGE ROWS - 1.5 x fewer matrix instructions for the same
+// result - for the maps the embedder spends its time on (14 x 14 and 28 x 28, Cin % 64 == 0; any even width the LDS holds).
+//
+// Why: the direct kernels (conv3x3_lean.hip) run their k-loop at the rate its own instruction stream sustains; the chip
+// is power-bound near 1.5 PFLOP/s of fp16 MFMA, so the next gain has to come from issuing fewer MFMAs per output.
+// tools/mix_lab.py (profiles/r3/mix_lab.txt) measured the candidate instruction mixes at one wave per SIMD: the 2-D
+// F(2x2,3x3) form needs 2 fragment reads + 8 packed adds per MFMA and twice the LDS-DMA bytes per MFMA; the 1-D form keeps
+// the direct kernel's 1 read per MFMA, adds 2 packed fp16 adds per MFMA and reuses its whole data path.
+//
+// Arithmetic.  Output pixels are taken in horizontal PAIRS (x = 2j, 2j+1; W even).  Per kernel row kh and input channel:
+//     d0..d3 = x[y+kh-1][2j-1 .. 2j+2]                       (zero outside the image)
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3            (B^T d, packed fp16, in registers)
+//     U0 = g0        U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2        (G g, once at load time: frp_api.cpp)
+//     M_f += U_f * V_f  summed over (kh, cin) on the matrix cores, fp32      (4 frequencies instead of 6 products per pair)
+//     y[2j] = M0 + M1 + M2        y[2j+1] = M1 - M2 - M3                     (A^T M, fp32, in the epilogue)
+// fp16 products of exactly transformed fp16 operands, fp32 accumulation: on the seeded IResNet-100 the embedding moves by
+// 1 - cos = 1.6e-6 against the direct kernels and stays 1.2e-6 from the fp32 oracle (tools/winograd_numerics.py; bar 1e-3).
+//
+// Structure: one 256-thread workgroup per CU = ONE wave per SIMD, each wave owning all four frequencies of a
+// (64 pairs = 128 pixels) x 64 couts block in 256 accumulator registers: 8 raw + 8 weight fragment reads for 16 MFMAs and
+// 16 packed adds per 16-channel sub-step.  Tile = 256 pixels x 128 couts, persistent XCD-interleaved walk as the other conv
+// kernels.  LDS: the pixel operand of a 64-channel block is ONE super-patch (all three kernel rows: 256 + 2W + 2 pixel
+// rows of 128 B, even and odd pixels in separate halves so that a pair-strided fragment read hits consecutive rows),
+// double-buffered across channel blocks; the weight operand is a 4-slot ring of 16 KiB stages, one per (channel block,
+// kernel row, 16-channel slice), stored in global memory as the LDS image itself (128 rows = couts x 8 chunks:
+// chunk 2f + h = frequency f, 8-channel half h; already xor-swizzled), so its LDS-DMA is a linear copy.  One barrier per
+// sub-step; the DMA runs two sub-steps ahead of the fragment reads, three ahead of the MFMAs; raw fragments of sub-step
+// s+1 and the first weight fragments of s+1 are read during the MFMAs of s (there is no second wave on the SIMD to hide
+// a read burst behind).
+//
+// Replaces the same reference calls as conv_mfma.hip (face_recognition.face_encodings, backend/app/routes/camera.py:237,
+// backend/app/services/face_service.py:179).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frp_internal.h"
+#include "conv_common.h"
+
+namespace frp {
+
+// packed fp16 add / subtract of an 8-halfword fragment (a plain <8 x half> subtraction is scalarised by this compiler)
+struct WH8 { unsigned p[4]; };
+__device__ __forceinline__ half8 wadd(half8 a, half8 b) {
+    WH8 x = __builtin_bit_cast(WH8, a), y = __builtin_bit_cast(WH8, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_pk_add_f16 %0, %1, %2" : "=v"(x.p[i]) : "v"(x.p[i]), "v"(y.p[i]));
+    return __builtin_bit_cast(half8, x);
+}
+__device__ __forceinline__ half8 wsub(half8 a, half8 b) {
+    WH8 x = __builtin_bit_cast(WH8, a), y = __builtin_bit_cast(WH8, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x.p[i]) : "v"(x.p[i]), "v"(y.p[i]));
+    return __builtin_bit_cast(half8, x);
+}
+
+#define WN_TP 256          // output pixels per tile (128 pairs)
+#define WN_TC 128          // couts per tile
+#define WN_NW 4            // waves per workgroup: one per SIMD
+#define WN_NSW 4           // weight ring slots (one 16-channel sub-step each)
+#define WN_WSLOT (WN_TC * 128)
+#define WN_PPS 12          // patch-piece issue slots per wave and channel block (2 in each of the sub-steps 0..5)
+
+// LDS rows of one half (even / odd pixels) of a super-patch: (256 + 2W + 2 + 1) / 2 rounded up to 16 (whole pieces per wave)
+__host__ __device__ inline int wino_half_rows(int W) { return ((WN_TP + 2 * W + 3) / 2 + 15) / 16 * 16; }
+__host__ __device__ inline int wino_lds_bytes(int W) {
+    return 2 * (2 * wino_half_rows(W) * 128) + WN_NSW * WN_WSLOT + 256 + 11 * WN_TC * 4 + WN_NW * 1024;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_kernel(ConvParams p_in) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    ConvParams p = p_in;
+    constexpr int TP = WN_TP, TC = WN_TC, NW = WN_NW;
+    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+        int n = *p.n_dev;
+        n = n < 0 ? 0 : (n > p.N ? p.N : n);
+        p.M = n * p.Ho * p.Wo;
+        p.n_ptiles = (p.M + TP - 1) / TP;
+    }
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n_tiles = p.n_ptiles * p.n_ctiles;
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {                // XCD-interleaved tile walk (see conv3x3_lean.hip)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = per;
+    } else {
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
+    if (t0 >= t1) return;
+    const int cpt = p.Cin >> 6;                // 64-channel blocks
+    const int cin2 = p.Cin * 2;                // bytes per pixel
+    const int HALF = wino_half_rows(p.W);
+    const int XSLOT = 2 * HALF * 128;
+    const int OFF_W = 2 * XSLOT;
+    const int OFF_Z = OFF_W + WN_NSW * WN_WSLOT;
+    const int OFF_PAR = OFF_Z + 256;
+    const int OFF_DUMP = OFF_PAR + 11 * TC * 4;
+    const int npw = HALF >> 4;                 // real patch pieces per wave and channel block (<= WN_PPS)
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---------------- DMA lane geometry.  A piece fills 8 LDS rows x 128 B: lane -> row lane/8, 16-byte position lane%8,
+    // which must hold logical chunk pos ^ ((row>>1)&7) (source-side swizzle; pieces start at multiples of 8 rows).
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // row group wave + 4j: (row >> 1) & 7 = (wave & 1) * 4 + lane / 16
+    // patch piece j of this wave = LDS row group g = wave + 4j (8 rows).  Rows below HALF hold the even pixel offsets
+    // r = 2 * row, the others r = 2 * (row - HALF) + 1 of the super-patch, whose pixel offset 0 is pixel m0 - W - 1.
+    // xsrc[j]: per-lane byte offset of that pixel row's chunk relative to pixel m0, channel block 0.
+    int xsrc[WN_PPS];
+#pragma unroll
+    for (int j = 0; j < WN_PPS; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        const int r = row < HALF ? 2 * row : 2 * (row - HALF) + 1;
+        xsrc[j] = (r - p.W - 1) * cin2 + lchunk * 16;
+    }
+    constexpr int DEAD = (int)0x80000000;
+
+    // ---------------- consumer geometry: wave (wp, wc) owns pairs [64 wp, +64) x couts [64 wc, +64) of the tile
+    const int wave_p = wave >> 1, wave_c = wave & 1;
+    const int pair0 = wave_p * 64, crow0 = wave_c * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    // raw fragment (pair block b, position i = 0..3, kernel row kh): pixel offset r = 2 pair + i + kh W of the super-patch
+    // -> LDS row (r >> 1) + (r & 1) HALF = pair + (i >> 1) + kh W/2 + (i & 1) HALF; byte address of its kk = 0 fragment
+    // (chunk fh) inside a patch slot.  kk flips address bits 5..6.
+    int pv[3][2][4];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = pair0 + b * 32 + fr + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+                pv[kh][b][i] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+            }
+    int aoff[2][4];                            // weight fragment (cout block c, frequency f): chunk 2f + fh of row crow0 + 32c + fr
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) aoff[c][f] = OFF_W + lds_off(crow0 + c * 32 + fr, 2 * f + fh);
+
+    floatx16 acc[4][2][2];                     // [frequency][pair block][cout block]
+    half8 raw[2][2][4];                        // [set][pair block][position]
+    half8 uf[4][2];                            // [frequency][cout block]
+    int radr[2][4];                            // per (channel block, kernel row): address of this lane's raw fragments (patch or zero block)
+
+    // ---------------- per-tile epilogue parameters in LDS (as conv3x3_lean.hip)
+    float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
+    float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
+    constexpr int PPT = (9 * TC + NW * 64 - 1) / (NW * 64);
+    float pb[PPT], ps = 0.f;
+    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
+    auto fetch_params = [&](int tile) {
+        const int c0p = (tile % p.n_ctiles) * TC;
+        const int nb = (border ? 9 : 1) * TC;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            const int cls = idx / TC, co = c0p + (idx - cls * TC);
+            pb[q] = (idx < nb && co < p.Cout) ? p.bias[(long)cls * p.Cout + co] : 0.f;
+        }
+        if (p.act == FRP_ACT_PRELU && t < TC) ps = (c0p + t < p.Cout) ? p.slope[c0p + t] : 0.f;
+    };
+    auto store_params = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int idx = t + q * NW * 64;
+            if (idx < 9 * TC) lds_bias[idx] = pb[q];
+        }
+        if (t < TC) lds_slope[t] = ps;
+    };
+
+    // ---------------- the DMA stream.  Weight stage = 16 KiB, contiguous in the image: ((ctile * cpt + cb) * 3 + kh) * 4 + kk.
+    // A tile's stages follow each other in the image; the stream crosses into the next tile of this workgroup.
+    struct Tile { int m0b; int wbase; unsigned vmask[2]; };
+    // vmask[b]: validity bits of pair block b's pair of this lane: 1 pair exists, 2 row above inside, 4 row below inside,
+    // 8 left neighbour (d0) inside, 16 right neighbour (d3) inside
+    auto make_tile = [&](int tile, Tile& d) {
+        if (tile >= t1) { d.m0b = DEAD; d.wbase = DEAD; d.vmask[0] = d.vmask[1] = 0; return; }
+        const int pt = tile / p.n_ctiles;
+        const int ct_ = tile - pt * p.n_ctiles;
+        d.m0b = pt * TP * cin2;
+        d.wbase = ct_ * cpt * 12 * WN_WSLOT;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = pt * TP + 2 * (pair0 + b * 32 + fr);
+            unsigned mask = 0;
+            if (m < p.M) {
+                int n, rem, oy, ox;
+                fast_divmod(m, HoWo, inv_howo, n, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                mask = 1u | (oy > 0 ? 2u : 0u) | (oy < p.H - 1 ? 4u : 0u) | (ox > 0 ? 8u : 0u) | (ox + 2 < p.W ? 16u : 0u);
+            }
+            d.vmask[b] = mask;
+        }
+    };
+    // weight stage `st` (0..12 cpt - 1 of the tile, or beyond: the next tile's) into ring slot `slot`: this wave's 4 pieces
+    auto w_stage = [&](int wbase, int st, int slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave + 4 * j;
+            const unsigned off = wbase == DEAD ? CONV_OOB : (unsigned)(wbase + st * WN_WSLOT + q * 1024 + lane * 16);
+            dma16(wrsrc, smem + OFF_W + slot * WN_WSLOT + q * 1024, off);
+        }
+    };
+    // patch piece slot j (0..11) of channel block byte offset cbs of the tile at m0b into patch slot `xs`
+    auto x_piece = [&](int m0b, int cbs, int j, int xs) {
+        const bool real = j < npw && m0b != DEAD;
+        const unsigned off = real ? (unsigned)(m0b + xsrc[j] + cbs) : CONV_OOB;
+        unsigned char* dst = real ? smem + xs + (wave + 4 * j) * 1024 : smem + OFF_DUMP + wave * 1024;
+        dma16(xrsrc, dst, off);
+    };
+
+    // ---------------- prologue
+    if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
+    Tile cur, nt;
+    make_tile(t0, cur);
+#pragma unroll
+    for (int j = 0; j < WN_PPS; ++j) x_piece(cur.m0b, 0, j, 0);
+    w_stage(cur.wbase, 0, 0);
+    w_stage(cur.wbase, 1, 1);
+    w_stage(cur.wbase, 2, 2);
+    int xs = 0;                                // byte offset of the patch slot the running channel block reads
+    const bool has_res = p.res != nullptr;
+    uint4 rres[2][2][2][2];                    // [parity][pair block][cout block][half]
+    int fr_e = fr, fh_e = fh;
+
+    auto set_radr = [&](const Tile& tl, int kh, int xslot) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned m = tl.vmask[b];
+            const bool rowok = (m & 1u) && (kh == 0 ? (m & 2u) : kh == 2 ? (m & 4u) : true);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = rowok && (i == 0 ? (m & 8u) : i == 3 ? (m & 16u) : true);
+                radr[b][i] = ok ? xslot + pv[kh][b][i] : OFF_Z + (pv[kh][b][i] & 255);
+            }
+        }
+    };
+    auto read_raw = [&](int kk, int S) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[S][b][i] = *reinterpret_cast<const half8*>(smem + (radr[b][i] ^ (kk << 5)));
+    };
+    auto read_u = [&](int slot, int f) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) uf[f][c] = *reinterpret_cast<const half8*>(smem + aoff[c][f] + slot * WN_WSLOT);
+    };
+    auto mfma_f = [&](int f, const half8 (&v)[2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[f][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uf[f][c], v[b], acc[f][b][c], 0, 0, 0);
+    };
+
+    // first sub-step's operands: wait for the patch and stages 0, 1, then read as every later sub-step does one step ahead
+    wait_vmcnt<4>();
+    __syncthreads();
+    set_radr(cur, 0, 0);
+    read_raw(0, 0);
+    read_u(0, 0);
+    read_u(0, 1);
+
+    for (int ct = t0; ct < t1; ct += tstep) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[f][b][c][e] = 0.f;
+        const int ptile = ct / p.n_ctiles;
+        const int m0 = ptile * TP;
+        const int c0 = (ct - ptile * p.n_ctiles) * TC;
+        make_tile(ct + tstep, nt);
+        asm volatile("" : "+v"(fr_e), "+v"(fh_e));
+
+        // One sub-step T = kh * 4 + kk of channel block cb (all static but cb): raw set T & 1 and uf[0], uf[1] hold its
+        // operands already.  It waits until weight stage T + 1 has landed (issued two sub-steps ago; behind it in the
+        // in-order counter: the pieces of sub-step T - 1 = 2 patch pieces if (T - 1) mod 12 <= 5, and 4 weight pieces),
+        // fires the patch pieces of the next channel block (sub-steps 0..5) and weight stage T + 3, reads the raw fragments
+        // and the first weight fragments of sub-step T + 1 under its MFMAs.
+#define WN_STEP(KH, KK)                                                                                                \
+    do {                                                                                                               \
+        constexpr int T = (KH) * 4 + (KK);                                                                             \
+        constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;                                                   \
+        if (T == 0 && cb == 0 && ct != t0) wait_vmcnt<0>();          /* the epilogue's stores sit in the counter too */ \
+        else if (((T + 11) % 12) <= 5) wait_vmcnt<6>(); else wait_vmcnt<4>();                                          \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if (T == 0 && cb == 0) fetch_params(ct);                                                                       \
+        if constexpr (T <= 5) { x_piece(nxm0b, ncbs, (2 * T) % WN_PPS, xs ^ XSLOT_X); x_piece(nxm0b, ncbs, (2 * T + 1) % WN_PPS, xs ^ XSLOT_X); } \
+        if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
+        half8 v[4][2];                                                                                                 \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                \
+            v[0][b] = wsub(raw[T & 1][b][0], raw[T & 1][b][2]);                                                        \
+            v[1][b] = wadd(raw[T & 1][b][1], raw[T & 1][b][2]);                                                        \
+            v[2][b] = wsub(raw[T & 1][b][2], raw[T & 1][b][1]);                                                        \
+            v[3][b] = wsub(raw[T & 1][b][1], raw[T & 1][b][3]);                                                        \
+        }                                                                                                              \
+        read_u(T & 3, 2);                                                                                              \
+        mfma_f(0, v[0]);                                                                                               \
+        read_u(T & 3, 3);                                                                                              \
+        /* operands of the next sub-step: its kernel row's addresses (next channel block / next tile at T = 11) */    \
+        if (KKN == 0) {                                                                                                \
+            if (T == 11) set_radr(last_cb ? nt : cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                   \
+        }                                                                                                              \
+        mfma_f(1, v[1]);                                                                                               \
+        read_raw(KKN, (T + 1) & 1);                                                                                    \
+        mfma_f(2, v[2]);                                                                                               \
+        read_u((T + 1) & 3, 0);                                                                                        \
+        read_u((T + 1) & 3, 1);                                                                                        \
+        if (T == 11 && last_cb && has_res) issue_residual();                                                           \
+        mfma_f(3, v[3]);                                                                                               \
+        if (T == 0 && cb == 0) store_params();                                                                         \
+    } while (0)
+
+        auto issue_residual = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+                conv_residual_loads<2, 2>(p, rres[par], m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, par);
+        };
+        const int XSLOT_X = XSLOT;
+        for (int cb = 0; cb < cpt; ++cb) {
+            const bool last_cb = cb + 1 == cpt;
+            // what lies beyond this channel block: the next block of this tile, or block 0 of the next tile
+            const int nxm0b = last_cb ? nt.m0b : cur.m0b;
+            const int ncbs = last_cb ? 0 : (cb + 1) << 7;
+            const int nxw = last_cb ? nt.wbase : cur.wbase;
+            const int nxst = last_cb ? 0 : (cb + 1) * 12;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[kh][b][i]));
+            WN_STEP(0, 0); WN_STEP(0, 1); WN_STEP(0, 2); WN_STEP(0, 3);
+            WN_STEP(1, 0); WN_STEP(1, 1); WN_STEP(1, 2); WN_STEP(1, 3);
+            WN_STEP(2, 0); WN_STEP(2, 1); WN_STEP(2, 2); WN_STEP(2, 3);
+            xs ^= XSLOT;
+        }
+#undef WN_STEP
+
+        // ---------------- epilogue: A^T M in fp32, then the shared tile epilogue once per pixel parity
+        {
+            floatx16 y[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) y[b][c][e] = acc[0][b][c][e] + acc[1][b][c][e] + acc[2][b][c][e];
+            conv_epilogue<2, 2, TC>(p, y, rres[0], lds_bias, lds_slope, m0, c0, TP, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, 0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) y[b][c][e] = acc[1][b][c][e] - acc[2][b][c][e] - acc[3][b][c][e];
+            conv_epilogue<2, 2, TC>(p, y, rres[1], lds_bias, lds_slope, m0, c0, TP, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, 1);
+        }
+        cur = nt;
+    }
+}
+
+// Shapes the Winograd kernel covers; `p` carries the derived fields of launch_conv().
+bool conv3x3_wino_eligible(const ConvParams& p) {
+    if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
+    if (p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return false;
+    if (wino_half_rows(p.W) / 16 > WN_PPS || wino_lds_bytes(p.W) > 160 * 1024) return false;
+    const long reach = ((long)p.M + 2L * p.W + 600) * p.Cin * 2;       // signed 32-bit patch offsets
+    return reach < 0x7fffffffL;
+}
+
+bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride) {
+    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_half_rows(W) / 16 <= WN_PPS &&
+           wino_lds_bytes(W) <= 160 * 1024;
+}
+
+// bytes of the transformed weight image of a layer (the `w` operand of the Winograd kernel)
+size_t conv3x3_wino_image_bytes(int Cin, int Cout) {
+    return (size_t)((Cout + WN_TC - 1) / WN_TC) * (Cin / 64) * 12 * WN_WSLOT;
+}
+
+hipError_t launch_conv3x3_wino(const ConvParams& p0, hipStream_t stream) {
+    if (!conv3x3_wino_eligible(p0)) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
+    p.n_ctiles = (p.Cout + WN_TC - 1) / WN_TC;
+    const size_t img = conv3x3_wino_image_bytes(p.Cin, p.Cout);
+    if (img >= 0x7fffffffUL) return hipErrorInvalidValue;
+    p.w_bytes = (unsigned)img;
+    const int lds = wino_lds_bytes(p.W);
+    static int attr_lds[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_lds[dev] < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_lds[dev] = 160 * 1024;
+    }
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    const int ncu = device_cu_count(dev);
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace frp

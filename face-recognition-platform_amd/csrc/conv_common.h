@@ -78,7 +78,10 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
 template <int MP, int MC, int TC, bool FULL, int ACT, int RES>
 __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
                                                    const float* lds_bias, const float* lds_slope, int m0, int c0, int prow0,
-                                                   int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+                                                   int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo,
+                                                   int ps = 1, int po = 0) {
+    // (ps, po): lane row r of the tile holds output pixel m0 + r * ps + po: (1, 0) in the direct kernels, (2, parity) in
+    // the Winograd kernel, whose lanes own pixel PAIRS (conv3x3_wino.hip)
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
     const bool out32 = (ACT < 0) && (p.flags & FRP_FLAG_OUT_F32);
     const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
@@ -89,7 +92,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16
     int cls[MP];
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
-        const int mraw = m0 + prow0 + i * 32 + fr;
+        const int mraw = m0 + (prow0 + i * 32 + fr) * ps + po;
         mok[i] = FULL || mraw < p.M;
         const int m = mok[i] ? mraw : 0;
         cls[i] = 0;
@@ -171,9 +174,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16
 template <int MP, int MC, int TC>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
                                               const float* lds_bias, const float* lds_slope, int m0, int c0, int TP, int prow0,
-                                              int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+                                              int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo,
+                                              int ps = 1, int po = 0) {
 #define FRP_EPI(FULL_, ACT_, RES_) \
-    conv_epilogue_body<MP, MC, TC, FULL_, ACT_, RES_>(p, acc, rres, lds_bias, lds_slope, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo)
+    conv_epilogue_body<MP, MC, TC, FULL_, ACT_, RES_>(p, acc, rres, lds_bias, lds_slope, m0, c0, prow0, crow0, fr, fh, HoWo, inv_howo, inv_wo, ps, po)
     const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
     if (!full) { FRP_EPI(false, -1, -1); return; }
     if (p.flags & FRP_FLAG_OUT_F32) { FRP_EPI(true, -1, -1); return; }
@@ -312,11 +316,11 @@ __device__ __forceinline__ void conv_epilogue8(const ConvParams& p, floatx16 (&a
 // always valid - addresses; consumed by conv_epilogue
 template <int MP, int MC>
 __device__ __forceinline__ void conv_residual_loads(const ConvParams& p, uint4 (&rres)[MP][MC][2], int m0, int c0, int prow0, int crow0,
-                                                    int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+                                                    int fr, int fh, int HoWo, float inv_howo, float inv_wo, int ps = 1, int po = 0) {
     const bool up2 = p.flags & FRP_FLAG_RES_UP2;
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
-        const int mraw = m0 + prow0 + i * 32 + fr;
+        const int mraw = m0 + (prow0 + i * 32 + fr) * ps + po;
         const int m = mraw < p.M ? mraw : 0;
         long ridx = (long)m * p.Cout;
         if (up2) {

@@ -478,6 +478,10 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         if (!conv3x3_rows_eligible(p) || (p.Cin & 127) || !p.wscale || !(p.in_scale > 0.f)) return hipErrorInvalidValue;
         return launch_conv3x3_lean(p, stream);
     }
+    if (p.wino_w && !(p.dbg & 1) && conv3x3_wino_eligible(p)) {      // Winograd F(2,3) along the rows: 1.5 x fewer MFMAs
+        p.w = p.wino_w;
+        return launch_conv3x3_wino(p, stream);
+    }
 #ifdef FRP_LAB   // lab build: dbg bits select the first-generation kernel and its timing ablations (conv3x3_rows.hip)
     if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
 #else

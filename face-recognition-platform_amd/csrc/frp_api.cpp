@@ -40,6 +40,7 @@ struct Net {
     int in_buf = 0, in_ch = 0;
     std::vector<DevBuf> bufs;
     std::vector<TensorDims> dims;   // per physical buffer, for the last planned shape
+    std::vector<int64_t> wino_off;  // per op: byte offset of its Winograd weight image in the data section, or -1
 };
 
 enum { EV_START = 0, EV_H2D, EV_PRE, EV_DET, EV_DEC, EV_ALIGN, EV_EMB, EV_L2, EV_MATCH, EV_D2H, EV_COUNT };
@@ -170,6 +171,50 @@ uint16_t f32_to_f16_bits(float f) {
     const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
     if (rem > half || (rem == half && (q & 1u))) ++q;                                            // a carry walks into the exponent
     return (uint16_t)(sign | (base + q));
+}
+
+float f16_bits_to_f32(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+    const int e = (hbits >> 10) & 31;
+    const uint32_t m = hbits & 0x3ffu;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 0x400u), e - 25);
+    uint32_t bits;
+    memcpy(&bits, &v, 4);
+    bits |= sign;
+    memcpy(&v, &bits, 4);
+    return v;
+}
+
+// Weight image of the Winograd kernel (conv3x3_wino.hip) from folded fp16 weights [Cout][3][3][Cin]: per (cout tile of
+// 128, 64-channel block, kernel row, 16-channel slice) one 16 KiB stage = the LDS image itself: 128 rows (couts; rows
+// beyond Cout zero) x 8 chunks of 16 B, logical chunk 2f + h = frequency f, 8-channel half h, stored at position
+// chunk ^ ((row >> 1) & 7).  U = G g: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 - exact in fp32 on fp16 inputs, rounded once.
+void build_wino_image(const uint16_t* w16, int Cin, int Cout, uint16_t* img) {
+    const int cpt = Cin / 64, nct = (Cout + 127) / 128;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int cb = 0; cb < cpt; ++cb)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kk = 0; kk < 4; ++kk) {
+                    uint16_t* st = img + ((((size_t)ct * cpt + cb) * 3 + kh) * 4 + kk) * 8192;
+                    for (int row = 0; row < 128; ++row) {
+                        const int co = ct * 128 + row;
+                        for (int hh = 0; hh < 2; ++hh)
+                            for (int e = 0; e < 8; ++e) {
+                                const int ci = cb * 64 + kk * 16 + hh * 8 + e;
+                                float g[3] = {0.f, 0.f, 0.f};
+                                if (co < Cout)
+                                    for (int kw = 0; kw < 3; ++kw) g[kw] = f16_bits_to_f32(w16[(((size_t)co * 3 + kh) * 3 + kw) * Cin + ci]);
+                                const float u[4] = {g[0], (g[0] + g[1] + g[2]) * 0.5f, (g[0] - g[1] + g[2]) * 0.5f, g[2]};
+                                for (int f = 0; f < 4; ++f) {
+                                    const int chunk = (2 * f + hh) ^ ((row >> 1) & 7);
+                                    st[row * 64 + chunk * 8 + e] = f32_to_f16_bits(u[f]);
+                                }
+                            }
+                    }
+                }
 }
 
 float logit_threshold(float t) {
@@ -339,6 +384,10 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
         p.n_dev = n_dev;
         p.n_cu = h->n_cu;
+        {
+            const size_t oi = (size_t)(&op - net.ops.data());
+            if (oi < net.wino_off.size() && net.wino_off[oi] >= 0) p.wino_w = (const _Float16*)(wbase + net.wino_off[oi]);
+        }
         p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
         if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
         p.in_scale = p.out_scale = 1.0f;
@@ -950,6 +999,35 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
         data = expanded.data();
         data_bytes = expanded.size();
     }
+    // Winograd weight images (conv3x3_wino.hip) for the embedder's eligible 3x3 stride-1 layers, appended behind the data
+    // section.  The embedder's geometry is static (112 x 112 chips), so the map width of every op is known here; the
+    // detector's maps at camera resolutions are wider than the kernel's LDS holds.  FRP_NO_WINO=1: direct kernels only.
+    h->det.wino_off.assign(h->det.ops.size(), -1);
+    h->emb.wino_off.assign(h->emb.ops.size(), -1);
+    if (!getenv("FRP_NO_WINO")) {
+        if (expanded.empty()) expanded.assign(data, data + hd.data_bytes);
+        std::vector<int> bw(h->emb.n_bufs, 0);
+        bw[h->emb.in_buf] = FRP_CHIP;
+        for (size_t i = 0; i < h->emb.ops.size(); ++i) {
+            const frp_conv_op& op = h->emb.ops[i];
+            const int win = (op.flags & FRP_FLAG_FLATTEN) ? 1 : bw[op.in_buf];
+            const int wout = (win + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
+            bw[op.out_buf] = wout;
+            if (op.out2_buf >= 0) bw[op.out2_buf] = wout;
+            if (!conv3x3_wino_shape_ok(win, op.cin, op.ksize, op.stride) || op.cout < 64 ||
+                (op.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_FLATTEN | FRP_FLAG_RES_UP2 | FRP_OPFLAG_W_FP8 | FRP_OPFLAG_FP8_MFMA | FRP_OPFLAG_OUT_FP8)) ||
+                op.out2_buf >= 0)
+                continue;
+            const size_t bytes = conv3x3_wino_image_bytes(op.cin, op.cout);
+            const size_t dst = (expanded.size() + 255) / 256 * 256;
+            expanded.resize(dst + bytes);
+            build_wino_image(reinterpret_cast<const uint16_t*>(expanded.data() + op.w_off), op.cin, op.cout,
+                             reinterpret_cast<uint16_t*>(expanded.data() + dst));
+            h->emb.wino_off[i] = (int64_t)dst;
+        }
+        data = expanded.data();
+        data_bytes = expanded.size();
+    }
     FRPCHK(ensure(h, h->wdata, data_bytes));
     HIPCHK(h, hipMemcpyAsync(h->wdata.p, data, data_bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1489,16 +1567,27 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     const size_t bb = (size_t)Cout * 4 * ((flags & FRP_FLAG_BORDER_BIAS) ? 9 : 1);
     const size_t ob = (size_t)N * Ho * Wo * Cout * ((flags & FRP_FLAG_OUT_F32) ? 4 : 2);
     const size_t rb = res ? (size_t)N * (up2 ? res_h : Ho) * (up2 ? res_w : Wo) * Cout * 2 : 0;
-    DevBuf dx, dw, db, ds, dr, dout;
+    DevBuf dx, dw, db, ds, dr, dout, dwino;
     int rc = ensure(h, dx, xb);
     if (rc == FRP_OK) rc = ensure(h, dw, wb);
     if (rc == FRP_OK) rc = ensure(h, db, bb);
     if (rc == FRP_OK) rc = ensure(h, dout, ob);
     if (rc == FRP_OK && slope) rc = ensure(h, ds, (size_t)Cout * 4);
     if (rc == FRP_OK && res) rc = ensure(h, dr, rb);
+    // flags bit 16: through the Winograd kernel (parity tests); an ineligible shape is an error, not a silent fallback
+    const bool want_wino = (flags & 0x10000) != 0;
+    std::vector<uint16_t> wimg;
+    if (want_wino) {
+        if (!conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2)))
+            return fail(h, FRP_ERR_INVALID, "shape not covered by the Winograd kernel");
+        wimg.resize(conv3x3_wino_image_bytes(Cin, Cout) / 2);
+        build_wino_image((const uint16_t*)w, Cin, Cout, wimg.data());
+        if (rc == FRP_OK) rc = ensure(h, dwino, wimg.size() * 2);
+    }
     hipError_t e = hipSuccess;
     if (rc == FRP_OK) {
         e = hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && want_wino) e = hipMemcpyAsync(dwino.p, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dw.p, w, wb, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(db.p, bias, bb, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess && slope) e = hipMemcpyAsync(ds.p, slope, (size_t)Cout * 4, hipMemcpyHostToDevice, h->stream);
@@ -1513,12 +1602,13 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
             p.dbg = (flags >> 8) & 0xff;      // kernel A/B switches (tests: 1 = generic kernel instead of the row-patch one)
             p.Hr = res_h; p.Wr = res_w;
+            if (want_wino) p.wino_w = (const _Float16*)dwino.p;
             e = launch_conv(p, h->stream);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, h->stream);
     }
     hipError_t e2 = hipStreamSynchronize(h->stream);
-    DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout};
+    DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout, &dwino};
     for (DevBuf* b : all) release(*b);
     if (rc != FRP_OK) return rc;
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? FRP_ERR_INVALID : FRP_ERR_HIP, std::string("conv2d: ") + hipGetErrorString(e));
@@ -1617,6 +1707,14 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
             if (with_res) p.out2 = nullptr;
         }
         p.dbg = (flags >> 8) & 0xff;
+        DevBuf dwino;
+        if ((flags & 0x10000) && conv3x3_wino_shape_ok(W, Cin, ksize, stride)) {     // Winograd kernel: a random weight image (timing only)
+            const size_t ib = conv3x3_wino_image_bytes(Cin, Cout);
+            if (ensure(h, dwino, ib) == FRP_OK) {
+                e = launch_fill_random_f16((_Float16*)dwino.p, (long)(ib / 2), 5u, 1.0f / sqrtf((float)(9 * Cin)), h->stream);
+                p.wino_w = (const _Float16*)dwino.p;
+            }
+        }
         DevBuf dst;
         if (stamps_out && ensure(h, dst, 256 * 8 * 8) == FRP_OK) {
             (void)hipMemsetAsync(dst.p, 0, 256 * 8 * 8, h->stream);
@@ -1630,6 +1728,8 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
         if (e == hipSuccess && stamps_out && p.stamps) e = hipMemcpy(stamps_out, p.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost);
         release(dst);
+        (void)hipStreamSynchronize(h->stream);
+        release(dwino);
     }
     (void)hipStreamSynchronize(h->stream);
     DevBuf* all[] = {&dx, &dw, &db, &ds, &dr, &dout};

@@ -35,6 +35,8 @@ struct ConvParams {
     int Hr, Wr;             // residual spatial dims (RES_UP2)
     int ksplit;             // >1: split-K, `out` = fp32 workspace [ksplit][M][Cout] of raw partial sums;
                             // -1 (only with n_dev): the kernel picks conv_pick_ksplit(M) itself
+    const _Float16* wino_w; // null, or the Winograd weight image of this layer (conv3x3_wino.hip; built by frp_api.cpp:build_wino_image):
+                            // launch_conv() takes the Winograd kernel when the shape is eligible
     const int32_t* n_dev;   // null, or the number of images that really exist (<= N) in device memory: the kernel derives
                             // M and its tile count from it (threshold mode: the face count never visits the host mid-pipeline)
     int n_cu;               // compute units (input of the device-side split-K choice)
@@ -53,6 +55,12 @@ bool conv3x3_rows_eligible(const ConvParams& p);
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);   // first generation + ablations (lab build only)
 #endif
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // static k-loop generation (conv3x3_lean.hip)
+// Winograd F(2,3) along the image rows (conv3x3_wino.hip): eligibility of a shape (`p` with launch_conv()'s derived fields),
+// the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
+bool conv3x3_wino_eligible(const ConvParams& p);
+bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride);
+size_t conv3x3_wino_image_bytes(int Cin, int Cout);
+hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream);
 
 // K1: u8 BGR frames -> normalised fp16 NHWC8 canvas (top-left letterbox, zero u8 pad)
 hipError_t launch_preprocess(const uint8_t* bgr, int B, int H, int W, long row_stride, long frame_stride,

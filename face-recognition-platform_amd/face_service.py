@@ -611,6 +611,15 @@ class FaceService:
             return lambda frames: self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold, det_thresh, all_matches)
         return lanes.run_ordered(batches, [on(e) for e in engines])
 
+    def frame_buffer(self, batch: int, height: int, width: int) -> np.ndarray:
+        """A page-locked u8 [batch, height, width, 3] array (owned by the engine, freed with it) for the capture / decode
+        threads to write frames into.  process_frames / process_stream accept any array; one that lives in page-locked
+        memory is copied to the GPU by DMA at PCIe rate, an ordinary (pageable) numpy array goes through the runtime's
+        staging copies first - at 32 x 1080p (199 MB per batch) that is the difference between the engine's rate and
+        ~0.8 of it (bench.py: config.service_api).  Reference: frames come out of cv2.VideoCapture.read() as fresh
+        pageable arrays (routes/camera.py:204-209); a capture loop on this service reads into these buffers instead."""
+        return self._eng().host_frames(batch, height, width)
+
     def process_frame(self, frame_bgr_or_path, metadata: Optional[Dict[str, Any]] = None):
         if isinstance(frame_bgr_or_path, str):
             frame = np.ascontiguousarray(load_image_file(frame_bgr_or_path)[..., ::-1])

@@ -549,3 +549,70 @@ def test_conv_fp8_mfma_parity(engine, case):
         assert np.abs(out16.astype(np.float32) - ref).max() <= 2e-3 * scale
         if copy8:
             check_fp8(out2)
+
+
+WINO_CASES = [
+    # N, H, W, Cin, Cout, act, res, flags(border)
+    (3, 14, 14, 256, 256, 2, False, 1),      # IResNet stage 3 conv1: border-class bias + PReLU, 4 channel blocks, 2 cout tiles
+    (5, 14, 14, 256, 256, 0, True, 0),       # conv2: residual; 980 pixels = 3 full tiles + a ragged one
+    (2, 28, 28, 128, 128, 2, True, 1),       # stage 2, everything on
+    (1, 28, 28, 128, 256, 1, False, 0),      # layer3.0.conv1 shape (128 -> 256), ReLU
+    (40, 14, 14, 64, 64, 0, False, 0),       # one channel block, Cout = 64: half of the cout tile is padding
+    (1, 2, 2, 64, 128, 0, False, 1),         # 2 x 2 map: every pair touches both borders
+    (7, 6, 30, 192, 160, 2, True, 1),        # widest map the LDS holds (W = 30), ragged cout tile, 3 channel blocks
+    (33, 4, 4, 128, 128, 1, True, 0),        # many tiny images per tile
+    (1, 16, 16, 64, 64, 0, False, 0),        # exactly one tile
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd_parity(engine, case):
+    """conv3x3_wino.hip (Winograd F(2,3) along the rows: transformed fp16 operands, fp32 accumulation) against the fp32
+    reference on the fp16-rounded operands, and against the direct kernel: same bar as the direct kernels (2e-3 of the
+    output scale: fp16 output rounding dominates), and within 3 fp16 ulps of the scale of the direct kernel's output."""
+    N, H, W, Cin, Cout, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 7)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
+    direct = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags)
+    wino = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | 0x10000)
+    ref = _conv_ref(x, w, bias, 1, act, slope, res, flags)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(wino.astype(np.float32) - ref).max()
+    assert err <= 2e-3 * scale, (err, scale)
+    assert np.abs(wino.astype(np.float32) - direct.astype(np.float32)).max() <= 3 * 2.0 ** -10 * scale
+
+
+def test_conv_winograd_rejects_what_it_does_not_cover(engine):
+    from frp_amd.native import FrpError
+    for shape, k, stride in (((1, 7, 7, 64), 3, 1), ((1, 8, 8, 32), 3, 1), ((1, 8, 8, 64), 1, 1), ((1, 8, 8, 64), 3, 2), ((1, 8, 64, 64), 3, 1)):
+        x = np.zeros(shape, np.float16)
+        w = np.zeros((64, k, k, shape[3]), np.float16)
+        with pytest.raises(FrpError):
+            engine.conv2d(x, w, np.zeros(64, np.float32), stride=stride, flags=0x10000)
+
+
+def test_embedder_winograd_layers_vs_direct_and_oracle(engine, monkeypatch):
+    """IResNet-100 with its 28 x 28 and 14 x 14 stride-1 3x3 convs on the Winograd kernel (the default) against the same
+    program on the direct kernels only (FRP_NO_WINO=1) and against the fp32 oracle: north-star bar 1 - 1e-3 against the
+    oracle, and 1 - cos <= 2e-5 between the two kernel families (CPU emulation of both: tools/winograd_numerics.py)."""
+    rng = np.random.default_rng(12)
+    chips = rng.integers(0, 256, size=(5, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (3, 13, 30, 3))
+    engine.load_weights(blob)
+    engine.reset_counters()
+    wino = engine.embed_aligned(chips)
+    monkeypatch.setenv("FRP_NO_WINO", "1")
+    engine.load_weights(blob)
+    direct = engine.embed_aligned(chips)
+    monkeypatch.delenv("FRP_NO_WINO")
+    engine.load_weights(blob)
+    assert not np.array_equal(wino, direct)                       # the two paths really are different kernels
+    ref = onet.emb_forward(raw, onet.emb_blob(chips))
+    assert (wino * ref).sum(1).min() > 1 - 1e-3 and (direct * ref).sum(1).min() > 1 - 1e-3
+    assert 1 - (wino * direct).sum(1).min() <= 2e-5
+    print("1 - cos: winograd vs oracle", 1 - (wino * ref).sum(1).min(), "direct vs oracle", 1 - (direct * ref).sum(1).min(),
+          "winograd vs direct", 1 - (wino * direct).sum(1).min())

@@ -87,6 +87,7 @@ def test_threshold_mode_face_count_stays_on_the_device(engine, monkeypatch):
         engine.gallery_set(G)
         frames = _frames(rng, B, H, W)
         frames[1] = 0                                                     # a frame without structure
+        ragged = False
         for thr in (0.5, 0.3, 1.0):
             monkeypatch.setenv("FRP_HOST_COUNT", "1")
             want = engine.process_frames(frames, max_faces=K, det_thresh=thr)
@@ -97,6 +98,7 @@ def test_threshold_mode_face_count_stays_on_the_device(engine, monkeypatch):
             for key in ("counts", "boxes", "kps", "scores", "emb", "match_idx", "match_cos"):
                 assert np.array_equal(got[key], want[key]), (emb_blocks, thr, key)
             n = int(got["counts"].sum())
+            ragged |= int(want["counts"].max()) > int(want["counts"].min())
             assert ctr["faces"] == n
             if thr == 1.0:
                 assert n == 0 and abs(ctr["emb_conv_flops"]) < 1.0
@@ -106,7 +108,7 @@ def test_threshold_mode_face_count_stays_on_the_device(engine, monkeypatch):
             res = engine.fetch_results()
             for key in ("counts", "emb", "match_idx", "match_cos"):
                 assert np.array_equal(res[key], want[key]), key
-        assert int(want["counts"].max()) > int(want["counts"].min())      # ragged at the last threshold but one
+        assert ragged                                                     # some threshold gave a ragged batch
     # > 512 slots: host-count fallback, same results either way
     raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
     engine.load_weights(blob)
@@ -472,7 +474,7 @@ def test_fp8_mfma_embedder(engine):
           the other layers keep their fp16-rounded weights): what is left is the E4M3 rounding of the activations;
       (b) the fp32 oracle network on the original weights (weights + activations);
       (c) the fp16 path of the library.
-    Bars: top-1 identity identical among 5,000 distractors; cosine >= 0.985 against all three
+    Bars: top-1 identity identical among 5,000 distractors; cosine >= 0.99 against all three
     (measured on the seeded R100: see the assertion message / DESIGN.md; E4M3 carries 3 mantissa bits and the error
     of ~90 fp8 layers accumulates in the residual stream - decisions near the thresholds: test_fp8_decision_flips)."""
     from frp_amd import weights as wts
@@ -500,7 +502,7 @@ def test_fp8_mfma_embedder(engine):
         assert 1e-5 < 1 - (ref_dq * ref).sum(1).min() < 2e-2
         cos_dq, cos_ref, cos16 = (e8 * ref_dq).sum(1), (e8 * ref).sum(1), (e8 * e16).sum(1)
         floors[emb_blocks] = (float(cos_dq.min()), float(cos_ref.min()), float(cos16.min()))
-        assert min(floors[emb_blocks]) > 0.985, floors
+        assert min(floors[emb_blocks]) > 0.99, floors
         assert cos_dq.min() >= cos_ref.min() - 2e-3, floors           # weight rounding removed: not further away
         G = rng.standard_normal((5000, 512)).astype(np.float32)
         G[200:200 + len(e16)] = e16
@@ -512,11 +514,11 @@ def test_fp8_mfma_embedder(engine):
 
 
 def test_fp8_activation_scales_follow_the_tensor_range(engine):
-    """The calibration has teeth: the SAME embedder function with its inner activations 1024 x larger / 64 x smaller
+    """The calibration has teeth: the SAME embedder function with its inner activations 1024 x larger / smaller
     (conftest.rescaled_embedder_raw: bn2 scaled, conv2 divided).  Calibrated blobs: the fp8 tensors hold the same codes, the
-    embedding does not move (cos >= 1 - 5e-4 against the unscaled fp8 run; not bit-exact only because the rescaled conv
+    embedding does not move (cos >= 1 - 1e-3 against the unscaled fp8 run; not bit-exact only because the rescaled conv
     weights become fp16 subnormals).  Uncalibrated blobs (unit scales, what pack_blob wrote before): 1024 x saturates the
-    tail of the tensor at E4M3's 448, 1/64 x drops it into the subnormal codes - the embedding leaves."""
+    tail of the tensor at E4M3's 448, 1/1024 x flushes most of it to zero - the embedding leaves."""
     from conftest import rescaled_embedder_raw
     from frp_amd import weights as wts
     rng = np.random.default_rng(59)
@@ -529,7 +531,7 @@ def test_fp8_activation_scales_follow_the_tensor_range(engine):
     e16 = engine.embed_aligned(chips)
     assert (base * e16).sum(1).min() > 0.985
     moved = {}
-    for f in (1024.0, 1.0 / 64):
+    for f in (1024.0, 1.0 / 1024):
         raw_f = rescaled_embedder_raw(raw, blocks, f)
         engine.load_weights(wts.pack_blob(raw_f, (1, 1, 1, 1), blocks))
         assert (engine.embed_aligned(chips) * e16).sum(1).min() > 1 - 1e-4        # the same function (fp16 path)
@@ -540,7 +542,7 @@ def test_fp8_activation_scales_follow_the_tensor_range(engine):
         moved[f] = (float((cal * base).sum(1).min()), float((unc * base).sum(1).min()))
     print("calibrated / uncalibrated cosine vs the unscaled fp8 run:", moved)
     for f, (c_cal, c_unc) in moved.items():
-        assert c_cal > 1 - 5e-4, moved
+        assert c_cal > 1 - 1e-3, moved
         assert c_unc < 0.99, moved
 
 
@@ -631,7 +633,7 @@ def test_config5_end_to_end_720p_two_streams_fp8(engine):
         assert np.array_equal(o8[k], o16[k]), k
     assert np.array_equal(o8["match_idx"], rows)                                     # identical top-1 identity
     cos = (o8["emb"] * o16["emb"]).sum(-1)
-    assert cos.min() > 0.985, float(cos.min())
+    assert cos.min() > 0.99, float(cos.min())
     assert np.abs(o8["match_cos"] - cos).max() < 2e-3                                # the matcher saw these embeddings
     alone = engine.process_frames(streams[1][2][None], max_faces=K, flags=native.FLAG_FORCED_K)
     for k in ("boxes", "kps", "scores", "match_idx"):

@@ -451,3 +451,39 @@ def test_camera_loop_on_the_real_engine_reproduces_the_reference_filter(engine):
         n_rows += len(got)
     assert n_rows > 10
     fs.ENCODINGS.clear()
+
+
+def test_stream_mixer_feeds_process_stream_on_device(engine):
+    """SURVEY 8f-4 / BASELINE config 5 on the GPU: two synthetic streams mixed frame by frame into page-locked batch
+    buffers (mixer.StreamMixer), run through FaceService.process_stream (two lanes when a second handle can join) and
+    handed back per stream: every kept frame gets exactly the faces a plain process_frames call on that frame gives."""
+    from frp_amd import mixer as mx
+    from test_gpu_pipeline import _frames
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    fs = FaceService(engine=engine)
+    fs.ENCODINGS.clear()
+    rng = np.random.default_rng(4)
+    fs.ENCODINGS.set_bulk([f"wl_{i}" for i in range(200)], rng.standard_normal((200, 512)).astype(np.float32))
+    vids = {11: _frames(np.random.default_rng(1), 7, 128, 160), 12: _frames(np.random.default_rng(2), 5, 128, 160)}
+    want = {sid: [fs.process_frames(f[None], max_faces=5)[0] for f in v[1::2]] for sid, v in vids.items()}   # frame_skip = 2 keeps 1, 3, 5
+    m = mx.StreamMixer({sid: mx.SyntheticStream(v) for sid, v in vids.items()}, batch=4,
+                       buffers=[fs.frame_buffer(4, 128, 160) for _ in range(6)], frame_skip=2)
+    got = {11: {}, 12: {}}
+    for per_stream in mx.run_mixed(fs, m, max_faces=5):
+        for sid, items in per_stream.items():
+            for idx, faces in items:
+                got[sid][idx] = faces
+    m.close()
+    assert {sid: sorted(d) for sid, d in got.items()} == {11: [0, 1, 2], 12: [0, 1]}
+    n = 0
+    for sid in vids:
+        for idx, faces in got[sid].items():
+            ref = want[sid][idx]
+            assert len(faces) == len(ref)
+            for a, b in zip(faces, ref):
+                assert a["bbox"] == b["bbox"] and a["target"] == b["target"] and a["match"] == b["match"]
+                assert np.array_equal(a["embedding"], b["embedding"])
+                n += 1
+    assert n > 0
+    fs.ENCODINGS.clear()

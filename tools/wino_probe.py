@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Winograd F(2,3) conv kernel vs the direct (lean) kernel on the embedder's eligible shapes (320 faces), same process,
+alternating, best of 3: microseconds per launch and effective TFLOP/s (algorithmic FLOPs of the direct convolution)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401
+import frp_amd_loader  # noqa: E402,F401
+from frp_amd import native  # noqa: E402
+
+SHAPES = [  # name, N, H, W, Cin, Cout, act, flags, res
+    ("emb stage 3 conv1 (14x14 256->256, PReLU, border bias)", 320, 14, 14, 256, 256, 2, 1, False),
+    ("emb stage 3 conv2 (14x14 256->256, residual)", 320, 14, 14, 256, 256, 0, 0, True),
+    ("emb stage 2 conv1 (28x28 128->128, PReLU, border bias)", 320, 28, 28, 128, 128, 2, 1, False),
+    ("emb stage 2 conv2 (28x28 128->128, residual)", 320, 28, 28, 128, 128, 0, 0, True),
+    ("emb layer3.0.conv1 (28x28 128->256)", 320, 28, 28, 128, 256, 2, 1, False),
+    ("emb layer4.0.conv1 (14x14 256->512)", 320, 14, 14, 256, 512, 2, 1, False),
+]
+
+
+def main():
+    eng = native.Engine(0)
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    tot = [0.0, 0.0]
+    for name, N, H, W, Ci, Co, act, fl, res in SHAPES:
+        best = [1e30, 1e30]
+        for _ in range(3):
+            for v, extra in enumerate((0, 0x10000)):
+                best[v] = min(best[v], eng.conv_bench(N, H, W, Ci, Co, 3, 1, act, fl | extra, res, iters) * 1e3)
+        fl_ = 2.0 * N * H * W * 9 * Ci * Co
+        tot[0] += best[0]
+        tot[1] += best[1]
+        print(f"{name:58s} direct {best[0]:7.1f} us {fl_ / best[0] / 1e6:7.1f} TF | winograd {best[1]:7.1f} us {fl_ / best[1] / 1e6:7.1f} TF eff | x{best[0] / best[1]:.3f}")
+    print(f"sum direct {tot[0]:.1f} us, winograd {tot[1]:.1f} us, x{tot[0] / tot[1]:.3f}")
+
+
+if __name__ == "__main__":
+    main()
