@@ -52,23 +52,79 @@ __device__ __forceinline__ half8 wsub(half8 a, half8 b) {
     return __builtin_bit_cast(half8, x);
 }
 
-#define WN_TP 256          // output pixels per tile (128 pairs)
-#define WN_TC 128          // couts per tile
-#define WN_NW 4            // waves per workgroup: one per SIMD
-#define WN_NSW 4           // weight ring slots (one 16-channel sub-step each)
-#define WN_WSLOT (WN_TC * 128)
-#define WN_PPS 12          // patch-piece issue slots per wave and channel block (2 in each of the sub-steps 0..5)
-
-// LDS rows of one half (even / odd pixels) of a super-patch: (256 + 2W + 2 + 1) / 2 rounded up to 16 (whole pieces per wave)
-__host__ __device__ inline int wino_half_rows(int W) { return ((WN_TP + 2 * W + 3) / 2 + 15) / 16 * 16; }
-__host__ __device__ inline int wino_lds_bytes(int W) {
-    return 2 * (2 * wino_half_rows(W) * 128) + WN_NSW * WN_WSLOT + 256 + 11 * WN_TC * 4 + WN_NW * 1024;
+#define WN_TC_ 128
+// Tile epilogue of the Winograd kernel: A^T M in fp32 (y_even = M0 + M1 + M2, y_odd = M1 - M2 - M3) and the shared per-block
+// epilogue body (bias / border-class bias, residual, activation, fp16 stores), ONE (32 pairs x 32 couts, parity) unit at
+// a time: 16 output registers and 8 residual registers live next to the accumulators (both parities of both cout blocks at
+// once - 64 + 64 registers - spilled, and a spilled epilogue took 19 us per tile).  The residual of unit u + 1 is requested
+// before unit u is finished.  Specialised at compile time on (full tile, activation, residual) like the direct kernels.
+// residual of one (cout block c, parity) unit in the store layout, from clamped - always valid - addresses
+template <int PB>
+__device__ __forceinline__ void wino_load_res(const ConvParams& p, uint4 (&r)[PB][1][2], int c, int par, int m0, int c0, int pair0,
+                                              int crow0, int fr, int fh) {
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int mraw = m0 + (pair0 + b * 32 + fr) * 2 + par;
+        const int m = mraw < p.M ? mraw : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int co = c0 + crow0 + c * 32 + 16 * q + 8 * fh;
+            r[b][0][q] = *reinterpret_cast<const uint4*>(p.res + (long)m * p.Cout + (co < p.Cout ? co : 0));
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_kernel(ConvParams p_in) {
+// (Requesting the first unit's residual under the tile's last MFMAs - 8 more live registers in the k-loop's last sub-step -
+// measured slower: 69.1 vs 66.2 us on the stage-3 shape.)
+template <int PB, bool FULL, int ACT, int RES>
+__device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16 (&acc)[4][PB][2],
+                                                   const float* lds_bias, const float* lds_slope, int m0, int c0, int pair0, int crow0,
+                                                   int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+    const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
+    uint4 rr[2][PB][1][2];
+    auto load_res = [&](int c, int par, uint4 (&r)[PB][1][2]) { wino_load_res<PB>(p, r, c, par, m0, c0, pair0, crow0, fr, fh); };
+    if (has_res) load_res(0, 0, rr[0]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = u >> 1, par = u & 1;
+        if (has_res && u < 3) load_res((u + 1) >> 1, (u + 1) & 1, rr[(u + 1) & 1]);
+        floatx16 y[PB][1];
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                y[b][0][e] = par ? (acc[1][b][c][e] - acc[2][b][c][e]) - acc[3][b][c][e] : (acc[0][b][c][e] + acc[1][b][c][e]) + acc[2][b][c][e];
+        conv_epilogue_body<PB, 1, WN_TC_, FULL, ACT, RES>(p, y, rr[u & 1], lds_bias, lds_slope, m0, c0, pair0, crow0 + c * 32, fr, fh, HoWo,
+                                                          inv_howo, inv_wo, 2, par);
+    }
+}
+
+#define WN_TP 256          // output pixels per tile (128 pairs)
+#define WN_TC 128          // couts per tile
+#define WN_NSW 4           // weight ring slots (one 16-channel sub-step each)
+#define WN_WSLOT (WN_TC * 128)
+#define WN_PIECES 48       // patch-piece issue slots per workgroup and channel block (spread over the sub-steps 0..5)
+
+// LDS rows of one half (even / odd pixels) of a super-patch: (256 + 2W + 2 + 1) / 2 rounded up to 32 (whole pieces per wave
+// for 4 and for 8 waves)
+__host__ __device__ inline int wino_half_rows(int W) { return ((WN_TP + 2 * W + 3) / 2 + 31) / 32 * 32; }
+__host__ __device__ inline int wino_lds_bytes(int W) {
+    return 2 * (2 * wino_half_rows(W) * 128) + WN_NSW * WN_WSLOT + 256 + 11 * WN_TC * 4 + 8 * 1024;
+}
+
+// NW = 4: one wave per SIMD, each owning 64 pairs x 64 couts x 4 frequencies in 256 accumulator registers (1 fragment read
+// per MFMA; the wave's own issue stream - 16 reads, 16 packed adds, 5 DMA pieces per 16 MFMAs - is what bounds it).
+// NW = 8: two waves per SIMD, 32 pairs x 64 couts x 4 frequencies in 128 accumulator registers each (1.5 reads per MFMA, but
+// the two issue streams of a SIMD overlap, as in the direct kernels).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
-    constexpr int TP = WN_TP, TC = WN_TC, NW = WN_NW;
+    constexpr int TP = WN_TP, TC = WN_TC;
+    constexpr int PB = 8 / NW;                 // 32-pair blocks per wave
+    constexpr int WPC = 16 / NW;               // weight pieces per wave and stage
+    constexpr int PPS = WN_PIECES / NW;        // patch-piece issue slots per wave and channel block
+    constexpr int PPT_STEP = PPS / 6;          // ... per sub-step (sub-steps 0..5)
     if (p.n_dev) {                             // image count known on the device only (threshold mode)
         int n = *p.n_dev;
         n = n < 0 ? 0 : (n > p.N ? p.N : n);
@@ -100,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int OFF_Z = OFF_W + WN_NSW * WN_WSLOT;
     const int OFF_PAR = OFF_Z + 256;
     const int OFF_DUMP = OFF_PAR + 11 * TC * 4;
-    const int npw = HALF >> 4;                 // real patch pieces per wave and channel block (<= WN_PPS)
+    const int npw = (HALF >> 2) / NW;          // real patch pieces per wave and channel block (<= PPS)
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -108,88 +164,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---------------- DMA lane geometry.  A piece fills 8 LDS rows x 128 B: lane -> row lane/8, 16-byte position lane%8,
     // which must hold logical chunk pos ^ ((row>>1)&7) (source-side swizzle; pieces start at multiples of 8 rows).
     const int lrow = lane >> 3;
-    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // row group wave + 4j: (row >> 1) & 7 = (wave & 1) * 4 + lane / 16
-    // patch piece j of this wave = LDS row group g = wave + 4j (8 rows).  Rows below HALF hold the even pixel offsets
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // row group wave + NW j: (row >> 1) & 7 = (wave & 1) * 4 + lane / 16
+    // patch piece j of this wave = LDS row group g = wave + NW j (8 rows).  Rows below HALF hold the even pixel offsets
     // r = 2 * row, the others r = 2 * (row - HALF) + 1 of the super-patch, whose pixel offset 0 is pixel m0 - W - 1.
-    // xsrc[j]: per-lane byte offset of that pixel row's chunk relative to pixel m0, channel block 0.
-    int xsrc[WN_PPS];
-#pragma unroll
-    for (int j = 0; j < WN_PPS; ++j) {
-        const int row = (wave + 4 * j) * 8 + lrow;
+    // x_src(j): per-lane byte offset of that pixel row's chunk relative to pixel m0, channel block 0 (recomputed per piece:
+    // a dozen scalar-ish operations against six registers held through the k-loop)
+    int lrow_e = lrow;                         // (made opaque per channel block: keeps x_src out of the registers / the spill slots)
+    auto x_src = [&](int j) -> int {
+        const int row = (wave + NW * j) * 8 + lrow_e;
         const int r = row < HALF ? 2 * row : 2 * (row - HALF) + 1;
-        xsrc[j] = (r - p.W - 1) * cin2 + lchunk * 16;
-    }
+        return (r - p.W - 1) * cin2 + lchunk * 16;
+    };
     constexpr int DEAD = (int)0x80000000;
 
-    // ---------------- consumer geometry: wave (wp, wc) owns pairs [64 wp, +64) x couts [64 wc, +64) of the tile
+    // ---------------- consumer geometry: wave (wp, wc) owns pairs [32 PB wp, +32 PB) x couts [64 wc, +64) of the tile
     const int wave_p = wave >> 1, wave_c = wave & 1;
-    const int pair0 = wave_p * 64, crow0 = wave_c * 64;
+    const int pair0 = wave_p * (32 * PB), crow0 = wave_c * 64;
     const int fr = lane & 31, fh = lane >> 5;
+    int fr_e = fr, fh_e = fh;                  // copies made opaque per tile / channel block (address arithmetic stays where it is used)
     const int HoWo = p.Ho * p.Wo;
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
     // raw fragment (pair block b, position i = 0..3, kernel row kh): pixel offset r = 2 pair + i + kh W of the super-patch
     // -> LDS row (r >> 1) + (r & 1) HALF = pair + (i >> 1) + kh W/2 + (i & 1) HALF; byte address of its kk = 0 fragment
     // (chunk fh) inside a patch slot.  kk flips address bits 5..6.
-    int pv[3][2][4];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = pair0 + b * 32 + fr + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
-                pv[kh][b][i] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
-            }
-    int aoff[2][4];                            // weight fragment (cout block c, frequency f): chunk 2f + fh of row crow0 + 32c + fr
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) aoff[c][f] = OFF_W + lds_off(crow0 + c * 32 + fr, 2 * f + fh);
+    auto pv_of = [&](int kh, int b, int i) -> int {
+        const int row = pair0 + b * 32 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+        return row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+    };
+    int aoff[2];                               // weight fragment (cout block c, frequency f): chunk 2f + fh of row crow0 + 32c + fr
+#pragma unroll                                 // = the f = 0 address with bits 5..6 flipped by f (2f + fh = 2f ^ fh: no carry)
+    for (int c = 0; c < 2; ++c) aoff[c] = OFF_W + lds_off(crow0 + c * 32 + fr, fh);
 
-    floatx16 acc[4][2][2];                     // [frequency][pair block][cout block]
-    half8 raw[2][2][4];                        // [set][pair block][position]
+    floatx16 acc[4][PB][2];                    // [frequency][pair block][cout block]
+    half8 raw[2][PB][4];                       // [set][pair block][position]
     half8 uf[4][2];                            // [frequency][cout block]
-    int radr[2][4];                            // per (channel block, kernel row): address of this lane's raw fragments (patch or zero block)
+    int radr[PB][4];                           // per (channel block, kernel row): address of this lane's raw fragments (patch or zero block)
 
-    // ---------------- per-tile epilogue parameters in LDS (as conv3x3_lean.hip)
+    // ---------------- per-tile epilogue parameters in LDS: bias [9][TC] (class-major; one class without border bias) and
+    // PReLU slope [TC], 5 KiB, brought in by LDS-DMA with per-lane global addresses at the first sub-step of a tile (one
+    // piece per wave: every wave must issue the same number of counted operations) - no registers, and no drain of the
+    // in-order counter as a register round trip (load, wait, ds_write) costs.  Couts beyond Cout and unused classes read
+    // clamped addresses: their values are never stored.
     float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
     float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
-    constexpr int PPT = (9 * TC + NW * 64 - 1) / (NW * 64);
-    float pb[PPT], ps = 0.f;
+    constexpr int PARP = (8 + NW - 1) / NW;                                 // parameter pieces per wave (5 real ones in all)
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
-    auto fetch_params = [&](int tile) {
+    auto dma_params = [&](int tile) {
         const int c0p = (tile % p.n_ctiles) * TC;
-        const int nb = (border ? 9 : 1) * TC;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int idx = t + q * NW * 64;
-            const int cls = idx / TC, co = c0p + (idx - cls * TC);
-            pb[q] = (idx < nb && co < p.Cout) ? p.bias[(long)cls * p.Cout + co] : 0.f;
+        for (int j = 0; j < PARP; ++j) {
+            const int q = wave + NW * j;
+            const int o = q * 1024 + lane * 16;
+            const char* src = reinterpret_cast<const char*>(p.bias);
+            if (o < 9 * TC * 4) {
+                const int cls = border ? o / (TC * 4) : 0;
+                int co = c0p + ((o % (TC * 4)) >> 2);
+                co = co + 4 <= p.Cout ? co : 0;
+                src = reinterpret_cast<const char*>(p.bias + (long)cls * p.Cout + co);
+            } else if (o < 10 * TC * 4 && p.slope) {
+                int co = c0p + ((o - 9 * TC * 4) >> 2);
+                co = co + 4 <= p.Cout ? co : 0;
+                src = reinterpret_cast<const char*>(p.slope + co);
+            }
+            unsigned char* dst = q < 5 ? smem + OFF_PAR + q * 1024 : smem + OFF_DUMP + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        if (p.act == FRP_ACT_PRELU && t < TC) ps = (c0p + t < p.Cout) ? p.slope[c0p + t] : 0.f;
-    };
-    auto store_params = [&]() {
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int idx = t + q * NW * 64;
-            if (idx < 9 * TC) lds_bias[idx] = pb[q];
-        }
-        if (t < TC) lds_slope[t] = ps;
     };
 
     // ---------------- the DMA stream.  Weight stage = 16 KiB, contiguous in the image: ((ctile * cpt + cb) * 3 + kh) * 4 + kk.
     // A tile's stages follow each other in the image; the stream crosses into the next tile of this workgroup.
-    struct Tile { int m0b; int wbase; unsigned vmask[2]; };
+    struct Tile { int m0b; int wbase; unsigned vmask[PB]; };
     // vmask[b]: validity bits of pair block b's pair of this lane: 1 pair exists, 2 row above inside, 4 row below inside,
     // 8 left neighbour (d0) inside, 16 right neighbour (d3) inside
     auto make_tile = [&](int tile, Tile& d) {
-        if (tile >= t1) { d.m0b = DEAD; d.wbase = DEAD; d.vmask[0] = d.vmask[1] = 0; return; }
+        if (tile >= t1) {
+            d.m0b = DEAD; d.wbase = DEAD;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) d.vmask[b] = 0;
+            return;
+        }
         const int pt = tile / p.n_ctiles;
         const int ct_ = tile - pt * p.n_ctiles;
         d.m0b = pt * TP * cin2;
         d.wbase = ct_ * cpt * 12 * WN_WSLOT;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < PB; ++b) {
             const int m = pt * TP + 2 * (pair0 + b * 32 + fr);
             unsigned mask = 0;
             if (m < p.M) {
@@ -201,79 +261,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             d.vmask[b] = mask;
         }
     };
-    // weight stage `st` (0..12 cpt - 1 of the tile, or beyond: the next tile's) into ring slot `slot`: this wave's 4 pieces
+    // weight stage `st` (0..12 cpt - 1 of the tile, or beyond: the next tile's) into ring slot `slot`: this wave's pieces
     auto w_stage = [&](int wbase, int st, int slot) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = wave + 4 * j;
+        for (int j = 0; j < WPC; ++j) {
+            const int q = wave + NW * j;
             const unsigned off = wbase == DEAD ? CONV_OOB : (unsigned)(wbase + st * WN_WSLOT + q * 1024 + lane * 16);
             dma16(wrsrc, smem + OFF_W + slot * WN_WSLOT + q * 1024, off);
         }
     };
-    // patch piece slot j (0..11) of channel block byte offset cbs of the tile at m0b into patch slot `xs`
+    // patch piece slot j (0..PPS-1) of channel block byte offset cbs of the tile at m0b into patch slot `xs`
     auto x_piece = [&](int m0b, int cbs, int j, int xs) {
         const bool real = j < npw && m0b != DEAD;
-        const unsigned off = real ? (unsigned)(m0b + xsrc[j] + cbs) : CONV_OOB;
-        unsigned char* dst = real ? smem + xs + (wave + 4 * j) * 1024 : smem + OFF_DUMP + wave * 1024;
+        const unsigned off = real ? (unsigned)(m0b + x_src(j) + cbs) : CONV_OOB;
+        unsigned char* dst = real ? smem + xs + (wave + NW * j) * 1024 : smem + OFF_DUMP + wave * 1024;
         dma16(xrsrc, dst, off);
     };
 
     // ---------------- prologue
+    stamp(p.stamps, 0);
     if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
     Tile cur, nt;
     make_tile(t0, cur);
 #pragma unroll
-    for (int j = 0; j < WN_PPS; ++j) x_piece(cur.m0b, 0, j, 0);
+    for (int j = 0; j < PPS; ++j) x_piece(cur.m0b, 0, j, 0);
     w_stage(cur.wbase, 0, 0);
     w_stage(cur.wbase, 1, 1);
     w_stage(cur.wbase, 2, 2);
     int xs = 0;                                // byte offset of the patch slot the running channel block reads
     const bool has_res = p.res != nullptr;
-    uint4 rres[2][2][2][2];                    // [parity][pair block][cout block][half]
-    int fr_e = fr, fh_e = fh;
 
     auto set_radr = [&](const Tile& tl, int kh, int xslot) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < PB; ++b) {
             const unsigned m = tl.vmask[b];
             const bool rowok = (m & 1u) && (kh == 0 ? (m & 2u) : kh == 2 ? (m & 4u) : true);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = rowok && (i == 0 ? (m & 8u) : i == 3 ? (m & 16u) : true);
-                radr[b][i] = ok ? xslot + pv[kh][b][i] : OFF_Z + (pv[kh][b][i] & 255);
+                const int a_ = pv_of(kh, b, i);
+                radr[b][i] = ok ? xslot + a_ : OFF_Z + (a_ & 255);
             }
         }
     };
     auto read_raw = [&](int kk, int S) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i) raw[S][b][i] = *reinterpret_cast<const half8*>(smem + (radr[b][i] ^ (kk << 5)));
     };
     auto read_u = [&](int slot, int f) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) uf[f][c] = *reinterpret_cast<const half8*>(smem + aoff[c][f] + slot * WN_WSLOT);
+        for (int c = 0; c < 2; ++c) uf[f][c] = *reinterpret_cast<const half8*>(smem + (aoff[c] ^ (f << 5)) + slot * WN_WSLOT);
     };
-    auto mfma_f = [&](int f, const half8 (&v)[2]) {
+    auto mfma_f = [&](int f, const half8 (&v)[PB]) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[f][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uf[f][c], v[b], acc[f][b][c], 0, 0, 0);
     };
 
     // first sub-step's operands: wait for the patch and stages 0, 1, then read as every later sub-step does one step ahead
-    wait_vmcnt<4>();
+    wait_vmcnt<WPC>();
     __syncthreads();
     set_radr(cur, 0, 0);
     read_raw(0, 0);
     read_u(0, 0);
     read_u(0, 1);
+    stamp(p.stamps, 1);
 
     for (int ct = t0; ct < t1; ct += tstep) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < PB; ++b)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -283,6 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int c0 = (ct - ptile * p.n_ctiles) * TC;
         make_tile(ct + tstep, nt);
         asm volatile("" : "+v"(fr_e), "+v"(fh_e));
+        if (ct == t0) stamp(p.stamps, 2);
 
         // One sub-step T = kh * 4 + kk of channel block cb (all static but cb): raw set T & 1 and uf[0], uf[1] hold its
         // operands already.  It waits until weight stage T + 1 has landed (issued two sub-steps ago; behind it in the
@@ -294,13 +356,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int T = (KH) * 4 + (KK);                                                                             \
         constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;                                                   \
         if (T == 0 && cb == 0 && ct != t0) wait_vmcnt<0>();          /* the epilogue's stores sit in the counter too */ \
-        else if (((T + 11) % 12) <= 5) wait_vmcnt<6>(); else wait_vmcnt<4>();                                          \
+        else if (T == 1 && cb == 0) wait_vmcnt<WPC + PPT_STEP + PARP>();   /* sub-step 0 of a tile also issued the parameter pieces */ \
+        else if (((T + 11) % 12) <= 5) wait_vmcnt<WPC + PPT_STEP>(); else wait_vmcnt<WPC>();                           \
         __builtin_amdgcn_s_barrier();                                                                                  \
-        if (T == 0 && cb == 0) fetch_params(ct);                                                                       \
-        if constexpr (T <= 5) { x_piece(nxm0b, ncbs, (2 * T) % WN_PPS, xs ^ XSLOT_X); x_piece(nxm0b, ncbs, (2 * T + 1) % WN_PPS, xs ^ XSLOT_X); } \
+        /* epilogue parameters of this tile: LDS-DMA, first in this sub-step's issue order (visible to all waves from the   \
+           barrier of sub-step 2 on; the previous tile's epilogue, their last reader, lies before this barrier) */       \
+        if (T == 0 && cb == 0) dma_params(ct);                                                                         \
+        if constexpr (T <= 5) {                                                                                        \
+            _Pragma("unroll") for (int q_ = 0; q_ < PPT_STEP; ++q_) x_piece(nxm0b, ncbs, (PPT_STEP * T + q_) % PPS, xs ^ XSLOT_X); \
+        }                                                                                                              \
         if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
-        half8 v[4][2];                                                                                                 \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                \
+        half8 v[4][PB];                                                                                                \
+        _Pragma("unroll") for (int b = 0; b < PB; ++b) {                                                               \
             v[0][b] = wsub(raw[T & 1][b][0], raw[T & 1][b][2]);                                                        \
             v[1][b] = wadd(raw[T & 1][b][1], raw[T & 1][b][2]);                                                        \
             v[2][b] = wsub(raw[T & 1][b][2], raw[T & 1][b][1]);                                                        \
@@ -310,24 +377,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         mfma_f(0, v[0]);                                                                                               \
         read_u(T & 3, 3);                                                                                              \
         /* operands of the next sub-step: its kernel row's addresses (next channel block / next tile at T = 11) */    \
-        if (KKN == 0) {                                                                                                \
-            if (T == 11) set_radr(last_cb ? nt : cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                   \
+        /* (not across a tile's epilogue: 32 more live registers there spill; the next tile reads them after it) */    \
+        const bool pf = !(T == 11 && last_cb);                                                                         \
+        if (KKN == 0 && pf) {                                                                                          \
+            if (T == 11) set_radr(cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                                  \
         }                                                                                                              \
         mfma_f(1, v[1]);                                                                                               \
-        read_raw(KKN, (T + 1) & 1);                                                                                    \
+        if (pf) read_raw(KKN, (T + 1) & 1);                                                                            \
         mfma_f(2, v[2]);                                                                                               \
-        read_u((T + 1) & 3, 0);                                                                                        \
-        read_u((T + 1) & 3, 1);                                                                                        \
-        if (T == 11 && last_cb && has_res) issue_residual();                                                           \
+        if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
         mfma_f(3, v[3]);                                                                                               \
-        if (T == 0 && cb == 0) store_params();                                                                         \
     } while (0)
 
-        auto issue_residual = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int par = 0; par < 2; ++par)
-                conv_residual_loads<2, 2>(p, rres[par], m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, par);
-        };
         const int XSLOT_X = XSLOT;
         for (int cb = 0; cb < cpt; ++cb) {
             const bool last_cb = cb + 1 == cpt;
@@ -336,39 +397,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int ncbs = last_cb ? 0 : (cb + 1) << 7;
             const int nxw = last_cb ? nt.wbase : cur.wbase;
             const int nxst = last_cb ? 0 : (cb + 1) * 12;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pv[kh][b][i]));
-            WN_STEP(0, 0); WN_STEP(0, 1); WN_STEP(0, 2); WN_STEP(0, 3);
+            asm volatile("" : "+v"(fr_e), "+v"(lrow_e));     // (opaque per channel block: the address arithmetic is not hoisted out of the loop)
+            WN_STEP(0, 0);
+            if (cb == 0 && ct == t0) stamp(p.stamps, 3);
+            WN_STEP(0, 1); WN_STEP(0, 2); WN_STEP(0, 3);
             WN_STEP(1, 0); WN_STEP(1, 1); WN_STEP(1, 2); WN_STEP(1, 3);
             WN_STEP(2, 0); WN_STEP(2, 1); WN_STEP(2, 2); WN_STEP(2, 3);
             xs ^= XSLOT;
         }
 #undef WN_STEP
 
-        // ---------------- epilogue: A^T M in fp32, then the shared tile epilogue once per pixel parity
+        if (ct == t0) stamp(p.stamps, 4);
+        // ---------------- epilogue (wino_tile_epilogue above)
         {
-            floatx16 y[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) y[b][c][e] = acc[0][b][c][e] + acc[1][b][c][e] + acc[2][b][c][e];
-            conv_epilogue<2, 2, TC>(p, y, rres[0], lds_bias, lds_slope, m0, c0, TP, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, 0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) y[b][c][e] = acc[1][b][c][e] - acc[2][b][c][e] - acc[3][b][c][e];
-            conv_epilogue<2, 2, TC>(p, y, rres[1], lds_bias, lds_slope, m0, c0, TP, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, 2, 1);
+#define WN_EPI(FULL_, ACT_, RES_) \
+    wino_tile_epilogue<PB, FULL_, ACT_, RES_>(p, acc, lds_bias, lds_slope, m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo)
+            const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
+            if (!full) WN_EPI(false, -1, -1);
+            else if (p.act == FRP_ACT_PRELU) { if (has_res) WN_EPI(true, FRP_ACT_PRELU, 1); else WN_EPI(true, FRP_ACT_PRELU, 0); }
+            else if (p.act == FRP_ACT_RELU) { if (has_res) WN_EPI(true, FRP_ACT_RELU, 1); else WN_EPI(true, FRP_ACT_RELU, 0); }
+            else { if (has_res) WN_EPI(true, FRP_ACT_NONE, 1); else WN_EPI(true, FRP_ACT_NONE, 0); }
+#undef WN_EPI
         }
         cur = nt;
+        if (ct + tstep < t1) {                 // first sub-step's operands of the next tile (its patch and stage 0 landed before this
+            set_radr(cur, 0, xs);              // tile's last barrier)
+            read_raw(0, 0);
+            read_u(0, 0);
+            read_u(0, 1);
+        }
+        if (ct == t0) stamp(p.stamps, 5);
     }
+    stamp(p.stamps, 6);
 }
 
 // Shapes the Winograd kernel covers; `p` carries the derived fields of launch_conv().
@@ -376,13 +436,13 @@ bool conv3x3_wino_eligible(const ConvParams& p) {
     if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
     if (p.Ho != p.H || p.Wo != p.W) return false;
     if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return false;
-    if (wino_half_rows(p.W) / 16 > WN_PPS || wino_lds_bytes(p.W) > 160 * 1024) return false;
+    if (wino_half_rows(p.W) / 4 > WN_PIECES || wino_lds_bytes(p.W) > 160 * 1024) return false;
     const long reach = ((long)p.M + 2L * p.W + 600) * p.Cin * 2;       // signed 32-bit patch offsets
     return reach < 0x7fffffffL;
 }
 
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride) {
-    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_half_rows(W) / 16 <= WN_PPS &&
+    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_half_rows(W) / 4 <= WN_PIECES &&
            wino_lds_bytes(W) <= 160 * 1024;
 }
 
@@ -391,8 +451,8 @@ size_t conv3x3_wino_image_bytes(int Cin, int Cout) {
     return (size_t)((Cout + WN_TC - 1) / WN_TC) * (Cin / 64) * 12 * WN_WSLOT;
 }
 
-hipError_t launch_conv3x3_wino(const ConvParams& p0, hipStream_t stream) {
-    if (!conv3x3_wino_eligible(p0)) return hipErrorInvalidValue;
+template <int NW>
+static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
     p.n_ctiles = (p.Cout + WN_TC - 1) / WN_TC;
@@ -404,7 +464,7 @@ hipError_t launch_conv3x3_wino(const ConvParams& p0, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (attr_lds[dev] < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_lds[dev] = 160 * 1024;
     }
@@ -413,8 +473,16 @@ hipError_t launch_conv3x3_wino(const ConvParams& p0, hipStream_t stream) {
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<NW>, dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
+    if (!conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
+#ifdef FRP_LAB   // dbg bit 32: the one-wave-per-SIMD configuration (A/B runs in the lab build; 0.7 x the speed of the default)
+    if (p.dbg & 32) return launch_wino_cfg<4>(p, stream);
+#endif
+    return launch_wino_cfg<8>(p, stream);
 }
 
 }  // namespace frp

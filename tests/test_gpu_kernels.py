@@ -584,6 +584,9 @@ def test_conv_winograd_parity(engine, case):
     err = np.abs(wino.astype(np.float32) - ref).max()
     assert err <= 2e-3 * scale, (err, scale)
     assert np.abs(wino.astype(np.float32) - direct.astype(np.float32)).max() <= 3 * 2.0 ** -10 * scale
+    # deterministic: a second launch gives the same bits
+    again = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | 0x10000)
+    assert np.array_equal(wino.view(np.uint16), again.view(np.uint16))
 
 
 def test_conv_winograd_rejects_what_it_does_not_cover(engine):

@@ -9,8 +9,9 @@ import frp_amd_loader  # noqa
 from frp_amd import native
 a = [int(x) for x in sys.argv[1:8]] if len(sys.argv) > 7 else [320, 14, 14, 256, 256, 3, 1]
 eng = native.Engine(0)
-res = len(sys.argv) > 8 and sys.argv[8] == "res"
-ms, st = eng.conv_bench(a[0], a[1], a[2], a[3], a[4], a[5], a[6], 0 if res else 2, 1, res, 20, stamps=True)
+res = len(sys.argv) > 8 and "res" in sys.argv[8:]
+extra = (0x10000 if "wino" in sys.argv[8:] else 0) | ((32 << 8) if "wino4" in sys.argv[8:] else 0)     # Winograd kernel (8 / 4 waves)
+ms, st = eng.conv_bench(a[0], a[1], a[2], a[3], a[4], a[5], a[6], 0 if res else 2, 1 | extra, res, 20, stamps=True)
 st = st[st[:, 0] > 0].astype(np.int64)
 t0 = st[:, 0].min()
 us = (st - t0) / 100.0

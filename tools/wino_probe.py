@@ -23,17 +23,18 @@ SHAPES = [  # name, N, H, W, Cin, Cout, act, flags, res
 def main():
     eng = native.Engine(0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for name, N, H, W, Ci, Co, act, fl, res in SHAPES:
-        best = [1e30, 1e30]
+        best = [1e30, 1e30, 1e30]
         for _ in range(3):
-            for v, extra in enumerate((0, 0x10000)):
+            for v, extra in enumerate((0, 0x10000, 0x10000 | (32 << 8))):     # direct, Winograd 2 waves per SIMD, 1 wave per SIMD
                 best[v] = min(best[v], eng.conv_bench(N, H, W, Ci, Co, 3, 1, act, fl | extra, res, iters) * 1e3)
         fl_ = 2.0 * N * H * W * 9 * Ci * Co
-        tot[0] += best[0]
-        tot[1] += best[1]
-        print(f"{name:58s} direct {best[0]:7.1f} us {fl_ / best[0] / 1e6:7.1f} TF | winograd {best[1]:7.1f} us {fl_ / best[1] / 1e6:7.1f} TF eff | x{best[0] / best[1]:.3f}")
-    print(f"sum direct {tot[0]:.1f} us, winograd {tot[1]:.1f} us, x{tot[0] / tot[1]:.3f}")
+        for v in range(3):
+            tot[v] += best[v]
+        print(f"{name:58s} direct {best[0]:7.1f} us {fl_ / best[0] / 1e6:7.1f} TF | winograd 8 waves {best[1]:7.1f} us {fl_ / best[1] / 1e6:7.1f} TF eff "
+              f"x{best[0] / best[1]:.3f} | 4 waves {best[2]:7.1f} us x{best[0] / best[2]:.3f}")
+    print(f"sum direct {tot[0]:.1f} us, winograd 8 waves {tot[1]:.1f} us x{tot[0] / tot[1]:.3f}, 4 waves {tot[2]:.1f} us x{tot[0] / tot[2]:.3f}")
 
 
 if __name__ == "__main__":
