@@ -116,7 +116,9 @@ __host__ __device__ inline int wino_lds_bytes(int W) {
 // per MFMA; the wave's own issue stream - 16 reads, 16 packed adds, 5 DMA pieces per 16 MFMAs - is what bounds it).
 // NW = 8: two waves per SIMD, 32 pairs x 64 couts x 4 frequencies in 128 accumulator registers each (1.5 reads per MFMA, but
 // the two issue streams of a SIMD overlap, as in the direct kernels).
-template <int NW>
+// ABL (lab build only; wrong results by design): timing ablations of the k-loop - 1 no MFMA, 2 no fragment reads, 4 no LDS-DMA,
+// 8 no barrier, 16 no B^T d arithmetic
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
@@ -169,11 +171,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     // r = 2 * row, the others r = 2 * (row - HALF) + 1 of the super-patch, whose pixel offset 0 is pixel m0 - W - 1.
     // x_src(j): per-lane byte offset of that pixel row's chunk relative to pixel m0, channel block 0 (recomputed per piece:
     // a dozen scalar-ish operations against six registers held through the k-loop)
-    int lrow_e = lrow;                         // (made opaque per channel block: keeps x_src out of the registers / the spill slots)
+    // = a per-lane constant (its row inside the piece, its chunk) + a per-piece scalar (HALF is a multiple of 32: a piece lies
+    // in one half): one vector add per piece
+    int lrow_e = lrow;                         // (unused now; kept opaque-able for A/B builds)
+    const int xlane = (2 * lrow - p.W - 1) * cin2 + lchunk * 16;
     auto x_src = [&](int j) -> int {
-        const int row = (wave + NW * j) * 8 + lrow_e;
-        const int r = row < HALF ? 2 * row : 2 * (row - HALF) + 1;
-        return (r - p.W - 1) * cin2 + lchunk * 16;
+        const int row0 = (wave + NW * j) * 8;                                      // scalar
+        const int r0 = row0 < HALF ? 2 * row0 : 2 * (row0 - HALF) + 1;
+        return xlane + r0 * cin2;
     };
     constexpr int DEAD = (int)0x80000000;
 
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     for (int c = 0; c < 2; ++c) aoff[c] = OFF_W + lds_off(crow0 + c * 32 + fr, fh);
 
     floatx16 acc[4][PB][2];                    // [frequency][pair block][cout block]
-    half8 raw[2][PB][4];                       // [set][pair block][position]
+    half8 raw[PB][4];                          // [pair block][position]: raw fragments of the NEXT sub-step
+    half8 vcur[4][PB];                         // [frequency][pair block]: B^T d of the running sub-step
     half8 uf[4][2];                            // [frequency][cout block]
     int radr[PB][4];                           // per (channel block, kernel row): address of this lane's raw fragments (patch or zero block)
 
@@ -262,12 +268,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         }
     };
     // weight stage `st` (0..12 cpt - 1 of the tile, or beyond: the next tile's) into ring slot `slot`: this wave's pieces
+    // (the stage / piece part of the source address rides in the SGPR offset operand - inside the image by construction -, the
+    // per-lane part is the constant lane * 16: no vector arithmetic per piece; past the last tile the lane offset is out of range)
     auto w_stage = [&](int wbase, int st, int slot) {
+        const unsigned voff = wbase == DEAD ? CONV_OOB : (unsigned)(lane * 16);
 #pragma unroll
         for (int j = 0; j < WPC; ++j) {
             const int q = wave + NW * j;
-            const unsigned off = wbase == DEAD ? CONV_OOB : (unsigned)(wbase + st * WN_WSLOT + q * 1024 + lane * 16);
-            dma16(wrsrc, smem + OFF_W + slot * WN_WSLOT + q * 1024, off);
+            if constexpr (!(ABL & 4))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + OFF_W + slot * WN_WSLOT + q * 1024), 16,
+                                                         voff, wbase == DEAD ? 0 : wbase + st * WN_WSLOT + q * 1024, 0, 0);
         }
     };
     // patch piece slot j (0..PPS-1) of channel block byte offset cbs of the tile at m0b into patch slot `xs`
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         const bool real = j < npw && m0b != DEAD;
         const unsigned off = real ? (unsigned)(m0b + x_src(j) + cbs) : CONV_OOB;
         unsigned char* dst = real ? smem + xs + (wave + NW * j) * 1024 : smem + OFF_DUMP + wave * 1024;
-        dma16(xrsrc, dst, off);
+        if constexpr (!(ABL & 4)) dma16(xrsrc, dst, off);
     };
 
     // ---------------- prologue
@@ -304,30 +314,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
             }
         }
     };
-    auto read_raw = [&](int kk, int S) {
+    auto read_raw = [&](int kk) {
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) raw[S][b][i] = *reinterpret_cast<const half8*>(smem + (radr[b][i] ^ (kk << 5)));
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (!(ABL & 2)) raw[b][i] = *reinterpret_cast<const half8*>(smem + (radr[b][i] ^ (kk << 5)));
+                else asm volatile("" : "+v"(raw[b][i]) : "v"(radr[b][i]));
+            }
+    };
+    auto transform_raw = [&]() {               // B^T d: V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            if constexpr (!(ABL & 16)) {
+                vcur[0][b] = wsub(raw[b][0], raw[b][2]);
+                vcur[1][b] = wadd(raw[b][1], raw[b][2]);
+                vcur[2][b] = wsub(raw[b][2], raw[b][1]);
+                vcur[3][b] = wsub(raw[b][1], raw[b][3]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) vcur[f][b] = raw[b][f];
+            }
+        }
     };
     auto read_u = [&](int slot, int f) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) uf[f][c] = *reinterpret_cast<const half8*>(smem + (aoff[c] ^ (f << 5)) + slot * WN_WSLOT);
+        for (int c = 0; c < 2; ++c) {
+            if constexpr (!(ABL & 2)) uf[f][c] = *reinterpret_cast<const half8*>(smem + (aoff[c] ^ (f << 5)) + slot * WN_WSLOT);
+            else asm volatile("" : "+v"(uf[f][c]) : "v"(aoff[c]));
+        }
     };
     auto mfma_f = [&](int f, const half8 (&v)[PB]) {
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[f][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uf[f][c], v[b], acc[f][b][c], 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                if constexpr (!(ABL & 1)) acc[f][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uf[f][c], v[b], acc[f][b][c], 0, 0, 0);
+                else asm volatile("" : "+v"(acc[f][b][c]) : "v"(uf[f][c]), "v"(v[b]));
+            }
     };
 
     // first sub-step's operands: wait for the patch and stages 0, 1, then read as every later sub-step does one step ahead
     wait_vmcnt<WPC>();
     __syncthreads();
     set_radr(cur, 0, 0);
-    read_raw(0, 0);
+    read_raw(0);
     read_u(0, 0);
     read_u(0, 1);
+    transform_raw();
     stamp(p.stamps, 1);
 
     for (int ct = t0; ct < t1; ct += tstep) {
@@ -358,7 +392,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         if (T == 0 && cb == 0 && ct != t0) wait_vmcnt<0>();          /* the epilogue's stores sit in the counter too */ \
         else if (T == 1 && cb == 0) wait_vmcnt<WPC + PPT_STEP + PARP>();   /* sub-step 0 of a tile also issued the parameter pieces */ \
         else if (((T + 11) % 12) <= 5) wait_vmcnt<WPC + PPT_STEP>(); else wait_vmcnt<WPC>();                           \
-        __builtin_amdgcn_s_barrier();                                                                                  \
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                                        \
+        /* V of this sub-step and uf[0], uf[1] are in registers: the matrix pipe starts right behind the barrier, everything  \
+           else of the step - DMA issue, fragment reads, the next step's B^T d - is placed between its MFMAs */        \
+        mfma_f(0, vcur[0]);                                                                                            \
+        read_u(T & 3, 2);                                                                                              \
+        read_u(T & 3, 3);                                                                                              \
+        /* operands of the next sub-step (not across a tile's epilogue: the registers held there spill; the next tile  \
+           reads them after it): its kernel row's addresses (next channel block at T = 11), its raw fragments */       \
+        const bool pf = !(T == 11 && last_cb);                                                                         \
+        if (KKN == 0 && pf) {                                                                                          \
+            if (T == 11) set_radr(cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                                  \
+        }                                                                                                              \
+        if (pf) read_raw(KKN);                                                                                         \
         /* epilogue parameters of this tile: LDS-DMA, first in this sub-step's issue order (visible to all waves from the   \
            barrier of sub-step 2 on; the previous tile's epilogue, their last reader, lies before this barrier) */       \
         if (T == 0 && cb == 0) dma_params(ct);                                                                         \
@@ -366,27 +412,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
             _Pragma("unroll") for (int q_ = 0; q_ < PPT_STEP; ++q_) x_piece(nxm0b, ncbs, (PPT_STEP * T + q_) % PPS, xs ^ XSLOT_X); \
         }                                                                                                              \
         if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
-        half8 v[4][PB];                                                                                                \
-        _Pragma("unroll") for (int b = 0; b < PB; ++b) {                                                               \
-            v[0][b] = wsub(raw[T & 1][b][0], raw[T & 1][b][2]);                                                        \
-            v[1][b] = wadd(raw[T & 1][b][1], raw[T & 1][b][2]);                                                        \
-            v[2][b] = wsub(raw[T & 1][b][2], raw[T & 1][b][1]);                                                        \
-            v[3][b] = wsub(raw[T & 1][b][1], raw[T & 1][b][3]);                                                        \
-        }                                                                                                              \
-        read_u(T & 3, 2);                                                                                              \
-        mfma_f(0, v[0]);                                                                                               \
-        read_u(T & 3, 3);                                                                                              \
-        /* operands of the next sub-step: its kernel row's addresses (next channel block / next tile at T = 11) */    \
-        /* (not across a tile's epilogue: 32 more live registers there spill; the next tile reads them after it) */    \
-        const bool pf = !(T == 11 && last_cb);                                                                         \
-        if (KKN == 0 && pf) {                                                                                          \
-            if (T == 11) set_radr(cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                                  \
-        }                                                                                                              \
-        mfma_f(1, v[1]);                                                                                               \
-        if (pf) read_raw(KKN, (T + 1) & 1);                                                                            \
-        mfma_f(2, v[2]);                                                                                               \
+        mfma_f(1, vcur[1]);                                                                                            \
+        mfma_f(2, vcur[2]);                                                                                            \
         if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
-        mfma_f(3, v[3]);                                                                                               \
+        mfma_f(3, vcur[3]);                                                                                            \
+        if (pf) transform_raw();                                                                                       \
     } while (0)
 
         const int XSLOT_X = XSLOT;
@@ -422,9 +452,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         cur = nt;
         if (ct + tstep < t1) {                 // first sub-step's operands of the next tile (its patch and stage 0 landed before this
             set_radr(cur, 0, xs);              // tile's last barrier)
-            read_raw(0, 0);
+            read_raw(0);
             read_u(0, 0);
             read_u(0, 1);
+            transform_raw();
         }
         if (ct == t0) stamp(p.stamps, 5);
     }
@@ -451,7 +482,7 @@ size_t conv3x3_wino_image_bytes(int Cin, int Cout) {
     return (size_t)((Cout + WN_TC - 1) / WN_TC) * (Cin / 64) * 12 * WN_WSLOT;
 }
 
-template <int NW>
+template <int NW, int ABL = 0>
 static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
@@ -464,7 +495,7 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (attr_lds[dev] < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((conv3x3_wino_kernel<NW, ABL>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_lds[dev] = 160 * 1024;
     }
@@ -473,7 +504,7 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
-    hipLaunchKernelGGL(conv3x3_wino_kernel<NW>, dim3(grid), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<NW, ABL>), dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -481,6 +512,20 @@ hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
 #ifdef FRP_LAB   // dbg bit 32: the one-wave-per-SIMD configuration (A/B runs in the lab build; 0.7 x the speed of the default)
     if (p.dbg & 32) return launch_wino_cfg<4>(p, stream);
+    switch ((p.dbg >> 1) & 15) {               // dbg bits 1..4: timing ablations (tools/wino_ablate.py)
+        case 1: return launch_wino_cfg<8, 1>(p, stream);
+        case 2: return launch_wino_cfg<8, 2>(p, stream);
+        case 4: return launch_wino_cfg<8, 4>(p, stream);
+        case 8: return launch_wino_cfg<8, 8>(p, stream);
+        case 3: return launch_wino_cfg<8, 3>(p, stream);
+        case 6: return launch_wino_cfg<8, 6>(p, stream);
+        case 5: return launch_wino_cfg<8, 5>(p, stream);
+        case 7: return launch_wino_cfg<8, 7>(p, stream);
+        case 12: return launch_wino_cfg<8, 12>(p, stream);
+        case 9: return launch_wino_cfg<8, 16>(p, stream);      // (code 9: no B^T d arithmetic)
+        case 15: return launch_wino_cfg<8, 31>(p, stream);     // everything off: the loop's own bookkeeping
+        default: break;
+    }
 #endif
     return launch_wino_cfg<8>(p, stream);
 }
