@@ -5,7 +5,7 @@
 # microarchitecture guide prescribes) summarised per kernel family, SQ counters of the stage-3 conv shape.
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/${1:-r2final}
+O=$R/gpurun_out/${1:-r3final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
@@ -27,6 +27,10 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
     SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq -o sq -- python3 $R/tools/conv_one.py 320 14 14 256 256 3 1 5 \
     > /dev/null 2> $O/sq.err
 echo "SQ pass done"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES \
+    SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sqw -o sq -- python3 $R/tools/conv_one.py 320 14 14 256 256 3 1 5 wino \
+    > /dev/null 2> $O/sqw.err
+echo "SQ pass (Winograd kernel) done"
 # the multi-GPU process shape on this one-GPU box: torch + RCCL initialised, gallery all-gather, two lanes
 (cd $R && FRP_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 10 --warmup 2 --cpu-frames 0 > $O/bench_dist_rehearsal_1rank.json 2> $O/bench_dist_rehearsal.err) || true
@@ -39,15 +43,16 @@ cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cp $(find $O/kt_timed -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats_one_batch_at_a_time.csv
 python - $O <<'PY'
 import csv, sys, glob
-f = glob.glob(sys.argv[1] + "/sq/**/*counter_collection.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-last = max(int(r["Dispatch_Id"]) for r in rows)
-with open(sys.argv[1] + "/conv_lean_stage3_sq_counters.csv", "w") as o:
-    w = csv.DictWriter(o, fieldnames=rows[0].keys())
-    w.writeheader()
-    for r in rows:
-        if int(r["Dispatch_Id"]) == last:
-            w.writerow(r)
+for d, out in (("sq", "conv_lean_stage3_sq_counters.csv"), ("sqw", "conv_wino_stage3_sq_counters.csv")):
+    f = glob.glob(sys.argv[1] + "/" + d + "/**/*counter_collection.csv", recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    with open(sys.argv[1] + "/" + out, "w") as o:
+        w = csv.DictWriter(o, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in rows:
+            if int(r["Dispatch_Id"]) == last:
+                w.writerow(r)
 PY
 tail -3 $O/layer_times.txt
 python - $O <<'PY'

@@ -8,5 +8,5 @@ import frp_amd_loader  # noqa
 from frp_amd import native
 a = [int(x) for x in sys.argv[1:9]]
 eng = native.Engine(0)
-ms = eng.conv_bench(a[0], a[1], a[2], a[3], a[4], a[5], a[6], 2, 1, False, a[7])
+ms = eng.conv_bench(a[0], a[1], a[2], a[3], a[4], a[5], a[6], 2, 1 | (0x10000 if "wino" in sys.argv[9:] else 0), False, a[7])   # "wino": the Winograd kernel
 print("ms", ms)
