@@ -405,18 +405,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
             if (T == 11) set_radr(cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                                  \
         }                                                                                                              \
         if (pf) read_raw(KKN);                                                                                         \
-        mfma_f(1, vcur[1]);                                                                                            \
-        mfma_f(2, vcur[2]);                                                                                            \
-        if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
-        /* the DMA pieces of this sub-step, late: behind the fragment reads (an LDS-DMA issued among pending ds_reads costs  \
-           2-3 x what it costs in a gap without them).  Epilogue parameters of this tile first in the issue order (visible  \
-           to all waves from the barrier of sub-step 2 on; the previous tile's epilogue, their last reader, lies before    \
-           this sub-step's barrier) */                                                                                 \
+        /* (the DMA pieces sit here, right behind the first MFMAs: issued late in the sub-step - behind the fragment reads, where  \
+           a piece is said to be cheapest - the six shapes ran at x1.10 instead of x1.13 of the direct kernel) */            \
+        /* epilogue parameters of this tile: LDS-DMA, first in this sub-step's issue order (visible to all waves from the   \
+           barrier of sub-step 2 on; the previous tile's epilogue, their last reader, lies before this barrier) */       \
         if (T == 0 && cb == 0) dma_params(ct);                                                                         \
         if constexpr (T <= 5) {                                                                                        \
             _Pragma("unroll") for (int q_ = 0; q_ < PPT_STEP; ++q_) x_piece(nxm0b, ncbs, (PPT_STEP * T + q_) % PPS, xs ^ XSLOT_X); \
         }                                                                                                              \
         if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
+        mfma_f(1, vcur[1]);                                                                                            \
+        mfma_f(2, vcur[2]);                                                                                            \
+        if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
         mfma_f(3, vcur[3]);                                                                                            \
         if (pf) transform_raw();                                                                                       \
     } while (0)
