@@ -16,17 +16,19 @@
 // fp16 products of exactly transformed fp16 operands, fp32 accumulation: on the seeded IResNet-100 the embedding moves by
 // 1 - cos = 1.6e-6 against the direct kernels and stays 1.2e-6 from the fp32 oracle (tools/winograd_numerics.py; bar 1e-3).
 //
-// Structure: one 256-thread workgroup per CU = ONE wave per SIMD, each wave owning all four frequencies of a
-// (64 pairs = 128 pixels) x 64 couts block in 256 accumulator registers: 8 raw + 8 weight fragment reads for 16 MFMAs and
-// 16 packed adds per 16-channel sub-step.  Tile = 256 pixels x 128 couts, persistent XCD-interleaved walk as the other conv
-// kernels.  LDS: the pixel operand of a 64-channel block is ONE super-patch (all three kernel rows: 256 + 2W + 2 pixel
-// rows of 128 B, even and odd pixels in separate halves so that a pair-strided fragment read hits consecutive rows),
-// double-buffered across channel blocks; the weight operand is a 4-slot ring of 16 KiB stages, one per (channel block,
-// kernel row, 16-channel slice), stored in global memory as the LDS image itself (128 rows = couts x 8 chunks:
-// chunk 2f + h = frequency f, 8-channel half h; already xor-swizzled), so its LDS-DMA is a linear copy.  One barrier per
-// sub-step; the DMA runs two sub-steps ahead of the fragment reads, three ahead of the MFMAs; raw fragments of sub-step
-// s+1 and the first weight fragments of s+1 are read during the MFMAs of s (there is no second wave on the SIMD to hide
-// a read burst behind).
+// Structure: one 512-thread workgroup per CU = two waves per SIMD, each wave owning all four frequencies of a
+// (32 pairs = 64 pixels) x 64 couts block in 128 accumulator registers: per 16-channel sub-step 8 MFMAs, 4 raw + 8 weight
+// fragment reads and 16 packed adds.  (The lab's one-wave-per-SIMD form - 64 pairs x 64 couts in 256 AGPRs, 1 read per MFMA -
+// is x0.7: a single issue stream per SIMD is longer than its matrix time; `conv3x3_wino_kernel<4>`, lab build only.)
+// Tile = 256 pixels x 128 couts, persistent XCD-interleaved walk as the other conv kernels.  LDS: the pixel operand of a
+// 64-channel block is ONE super-patch (all three kernel rows: 256 + 2W + 2 pixel rows of 128 B, even and odd pixels in
+// separate halves so that a pair-strided fragment read hits consecutive rows), double-buffered across channel blocks; the
+// weight operand is a 4-slot ring of 16 KiB stages, one per (channel block, kernel row, 16-channel slice), stored in global
+// memory as the LDS image itself (128 rows = couts x 8 chunks: chunk 2f + h = frequency f, 8-channel half h; already
+// xor-swizzled), so its LDS-DMA is a linear copy; the tile's epilogue parameters arrive by LDS-DMA too.  One barrier per
+// sub-step; the DMA runs two sub-steps ahead of the fragment reads, three ahead of the MFMAs; the raw fragments and the
+// first weight fragments of sub-step s+1 are read - and B^T d of s+1 is computed - during the MFMAs of s, so the matrix pipe
+// starts right behind every barrier.
 //
 // Replaces the same reference calls as conv_mfma.hip (face_recognition.face_encodings, backend/app/routes/camera.py:237,
 // backend/app/services/face_service.py:179).
@@ -103,7 +105,8 @@ __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16
 #define WN_TC 128          // couts per tile
 #define WN_NSW 4           // weight ring slots (one 16-channel sub-step each)
 #define WN_WSLOT (WN_TC * 128)
-#define WN_PIECES 48       // patch-piece issue slots per workgroup and channel block (spread over the sub-steps 0..5)
+#define WN_PIECES 48       // patch-piece issue slots per workgroup and patch
+#define WN_ROWP_HALF 160   // row patches: (256 + 2 + 1) / 2 rows per half, rounded up to 32
 
 // LDS rows of one half (even / odd pixels) of a super-patch: (256 + 2W + 2 + 1) / 2 rounded up to 32 (whole pieces per wave
 // for 4 and for 8 waves)
@@ -111,6 +114,9 @@ __host__ __device__ inline int wino_half_rows(int W) { return ((WN_TP + 2 * W + 
 __host__ __device__ inline int wino_lds_bytes(int W) {
     return 2 * (2 * wino_half_rows(W) * 128) + WN_NSW * WN_WSLOT + 256 + 11 * WN_TC * 4 + 8 * 1024;
 }
+// the super-patch of a channel block fits (W <= 30); wider maps take the row-patch form, whose LDS does not depend on W
+__host__ __device__ inline bool wino_super_patch(int W) { return wino_half_rows(W) / 4 <= WN_PIECES && wino_lds_bytes(W) <= 160 * 1024; }
+__host__ __device__ inline int wino_rowp_lds_bytes() { return 2 * (2 * WN_ROWP_HALF * 128) + WN_NSW * WN_WSLOT + 256 + 11 * WN_TC * 4 + 8 * 1024; }
 
 // NW = 4: one wave per SIMD, each owning 64 pairs x 64 couts x 4 frequencies in 256 accumulator registers (1 fragment read
 // per MFMA; the wave's own issue stream - 16 reads, 16 packed adds, 5 DMA pieces per 16 MFMAs - is what bounds it).
@@ -118,15 +124,22 @@ __host__ __device__ inline int wino_lds_bytes(int W) {
 // the two issue streams of a SIMD overlap, as in the direct kernels).
 // ABL (lab build only; wrong results by design): timing ablations of the k-loop - 1 no MFMA, 2 no fragment reads, 4 no LDS-DMA,
 // 8 no barrier, 16 no B^T d arithmetic
-template <int NW, int ABL = 0>
+// ROWP (lab build only - measured, not shipped): one patch per (channel block, KERNEL ROW) - 258 pixel rows whatever the map
+// width - in a two-slot ring fired one kernel row ahead, instead of the super-patch of a channel block: for maps too wide
+// for it (W > 30: the detector's).  Three times the patch bytes per channel block (the three row patches of a block overlap
+// in all but 2 W pixels), the same fragment reads - and with 3.5 instead of 2.4 LDS-DMA pieces per wave and sub-step it runs
+// at x0.87...0.99 of the DIRECT kernel on the detector's shapes (profiles/r3/wino_probe.txt): the DMA issue, already the
+// kernel's largest cost next to the matrix time, eats the 1.5 x fewer MFMAs.  Bit-identical to the super-patch form.
+template <int NW, int ABL = 0, bool ROWP = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
     constexpr int TP = WN_TP, TC = WN_TC;
     constexpr int PB = 8 / NW;                 // 32-pair blocks per wave
     constexpr int WPC = 16 / NW;               // weight pieces per wave and stage
-    constexpr int PPS = WN_PIECES / NW;        // patch-piece issue slots per wave and channel block
-    constexpr int PPT_STEP = PPS / 6;          // ... per sub-step (sub-steps 0..5)
+    constexpr int PPS = WN_PIECES / NW;        // patch-piece issue slots per wave and patch
+    constexpr int PPT_STEP = ROWP ? PPS / 2 : PPS / 6;   // ... per sub-step (super-patch: sub-steps 0..5 of a channel block; row patches:
+                                                         // sub-steps 0, 1 of every kernel row)
     if (p.n_dev) {                             // image count known on the device only (threshold mode)
         int n = *p.n_dev;
         n = n < 0 ? 0 : (n > p.N ? p.N : n);
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     if (t0 >= t1) return;
     const int cpt = p.Cin >> 6;                // 64-channel blocks
     const int cin2 = p.Cin * 2;                // bytes per pixel
-    const int HALF = wino_half_rows(p.W);
+    const int HALF = ROWP ? WN_ROWP_HALF : wino_half_rows(p.W);
     const int XSLOT = 2 * HALF * 128;
     const int OFF_W = 2 * XSLOT;
     const int OFF_Z = OFF_W + WN_NSW * WN_WSLOT;
@@ -173,8 +186,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     // a dozen scalar-ish operations against six registers held through the k-loop)
     // = a per-lane constant (its row inside the piece, its chunk) + a per-piece scalar (HALF is a multiple of 32: a piece lies
     // in one half): one vector add per piece
-    int lrow_e = lrow;                         // (unused now; kept opaque-able for A/B builds)
-    const int xlane = (2 * lrow - p.W - 1) * cin2 + lchunk * 16;
+    const int xlane = (2 * lrow - (ROWP ? 0 : p.W) - 1) * cin2 + lchunk * 16;   // (row patches: the kernel row's offset comes per patch)
     auto x_src = [&](int j) -> int {
         const int row0 = (wave + NW * j) * 8;                                      // scalar
         const int r0 = row0 < HALF ? 2 * row0 : 2 * (row0 - HALF) + 1;
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     // -> LDS row (r >> 1) + (r & 1) HALF = pair + (i >> 1) + kh W/2 + (i & 1) HALF; byte address of its kk = 0 fragment
     // (chunk fh) inside a patch slot.  kk flips address bits 5..6.
     auto pv_of = [&](int kh, int b, int i) -> int {
-        const int row = pair0 + b * 32 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+        const int row = pair0 + b * 32 + fr_e + (i >> 1) + (ROWP ? 0 : kh * (p.W >> 1)) + (i & 1) * HALF;
         return row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
     };
     int aoff[2];                               // weight fragment (cout block c, frequency f): chunk 2f + fh of row crow0 + 32c + fr
@@ -281,9 +293,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         }
     };
     // patch piece slot j (0..PPS-1) of channel block byte offset cbs of the tile at m0b into patch slot `xs`
-    auto x_piece = [&](int m0b, int cbs, int j, int xs) {
+    auto x_piece = [&](int m0b, int cbs, int j, int xs, int kh = 1) {
         const bool real = j < npw && m0b != DEAD;
-        const unsigned off = real ? (unsigned)(m0b + x_src(j) + cbs) : CONV_OOB;
+        const unsigned off = real ? (unsigned)(m0b + x_src(j) + cbs + (ROWP ? (kh - 1) * p.W * cin2 : 0)) : CONV_OOB;
         unsigned char* dst = real ? smem + xs + (wave + NW * j) * 1024 : smem + OFF_DUMP + wave * 1024;
         if constexpr (!(ABL & 4)) dma16(xrsrc, dst, off);
     };
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     Tile cur, nt;
     make_tile(t0, cur);
 #pragma unroll
-    for (int j = 0; j < PPS; ++j) x_piece(cur.m0b, 0, j, 0);
+    for (int j = 0; j < PPS; ++j) x_piece(cur.m0b, 0, j, 0, 0);
     w_stage(cur.wbase, 0, 0);
     w_stage(cur.wbase, 1, 1);
     w_stage(cur.wbase, 2, 2);
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;                                                   \
         if (T == 0 && cb == 0 && ct != t0) wait_vmcnt<0>();          /* the epilogue's stores sit in the counter too */ \
         else if (T == 1 && cb == 0) wait_vmcnt<WPC + PPT_STEP + PARP>();   /* sub-step 0 of a tile also issued the parameter pieces */ \
-        else if (((T + 11) % 12) <= 5) wait_vmcnt<WPC + PPT_STEP>(); else wait_vmcnt<WPC>();                           \
+        else if (ROWP ? (((T + 11) % 12) % 4) <= 1 : ((T + 11) % 12) <= 5) wait_vmcnt<WPC + PPT_STEP>(); else wait_vmcnt<WPC>(); \
         if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                                        \
         /* V of this sub-step and uf[0], uf[1] are in registers: the matrix pipe starts right behind the barrier, everything  \
            else of the step - DMA issue, fragment reads, the next step's B^T d - is placed between its MFMAs */        \
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
            reads them after it): its kernel row's addresses (next channel block at T = 11), its raw fragments */       \
         const bool pf = !(T == 11 && last_cb);                                                                         \
         if (KKN == 0 && pf) {                                                                                          \
-            if (T == 11) set_radr(cur, 0, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                                  \
+            if (T == 11 || ROWP) set_radr(cur, KHN, xs ^ XSLOT_X); else set_radr(cur, KHN, xs);                        \
         }                                                                                                              \
         if (pf) read_raw(KKN);                                                                                         \
         /* (the DMA pieces sit here, right behind the first MFMAs: issued late in the sub-step - behind the fragment reads, where  \
@@ -410,8 +422,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         /* epilogue parameters of this tile: LDS-DMA, first in this sub-step's issue order (visible to all waves from the   \
            barrier of sub-step 2 on; the previous tile's epilogue, their last reader, lies before this barrier) */       \
         if (T == 0 && cb == 0) dma_params(ct);                                                                         \
-        if constexpr (T <= 5) {                                                                                        \
+        if constexpr (!ROWP && T <= 5) {                                                                               \
             _Pragma("unroll") for (int q_ = 0; q_ < PPT_STEP; ++q_) x_piece(nxm0b, ncbs, (PPT_STEP * T + q_) % PPS, xs ^ XSLOT_X); \
+        }                                                                                                              \
+        if constexpr (ROWP && (KK) <= 1) {     /* the next kernel row's patch: row KH + 1 of this block, or row 0 of what lies beyond it */ \
+            _Pragma("unroll") for (int q_ = 0; q_ < PPT_STEP; ++q_) {                                                  \
+                if ((KH) < 2) x_piece(cur.m0b, cb << 7, (PPT_STEP * (KK) + q_) % PPS, xs ^ XSLOT_X, (KH) + 1);          \
+                else x_piece(nxm0b, ncbs, (PPT_STEP * (KK) + q_) % PPS, xs ^ XSLOT_X, 0);                              \
+            }                                                                                                          \
         }                                                                                                              \
         if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
         mfma_f(1, vcur[1]);                                                                                            \
@@ -419,6 +437,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
         mfma_f(3, vcur[3]);                                                                                            \
         if (pf) transform_raw();                                                                                       \
+        if (ROWP && (KK) == 3) xs ^= XSLOT_X;  /* row patches: the slots alternate per kernel row */                    \
     } while (0)
 
         const int XSLOT_X = XSLOT;
@@ -429,13 +448,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
             const int ncbs = last_cb ? 0 : (cb + 1) << 7;
             const int nxw = last_cb ? nt.wbase : cur.wbase;
             const int nxst = last_cb ? 0 : (cb + 1) * 12;
-            asm volatile("" : "+v"(fr_e), "+v"(lrow_e));     // (opaque per channel block: the address arithmetic is not hoisted out of the loop)
+            asm volatile("" : "+v"(fr_e));     // (opaque per channel block: the address arithmetic is not hoisted out of the loop)
             WN_STEP(0, 0);
             if (cb == 0 && ct == t0) stamp(p.stamps, 3);
             WN_STEP(0, 1); WN_STEP(0, 2); WN_STEP(0, 3);
             WN_STEP(1, 0); WN_STEP(1, 1); WN_STEP(1, 2); WN_STEP(1, 3);
             WN_STEP(2, 0); WN_STEP(2, 1); WN_STEP(2, 2); WN_STEP(2, 3);
-            xs ^= XSLOT;
+            if (!ROWP) xs ^= XSLOT;
         }
 #undef WN_STEP
 
@@ -469,14 +488,18 @@ bool conv3x3_wino_eligible(const ConvParams& p) {
     if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
     if (p.Ho != p.H || p.Wo != p.W) return false;
     if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return false;
-    if (wino_half_rows(p.W) / 4 > WN_PIECES || wino_lds_bytes(p.W) > 160 * 1024) return false;
+
+    if (!conv3x3_wino_shape_ok(p.W, p.Cin, p.KS, p.stride)) return false;
     const long reach = ((long)p.M + 2L * p.W + 600) * p.Cin * 2;       // signed 32-bit patch offsets
     return reach < 0x7fffffffL;
 }
 
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride) {
-    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_half_rows(W) / 4 <= WN_PIECES &&
-           wino_lds_bytes(W) <= 160 * 1024;
+#ifdef FRP_LAB
+    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2;      // (wide maps: the row-patch form, lab build)
+#else
+    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_super_patch(W);
+#endif
 }
 
 // bytes of the transformed weight image of a layer (the `w` operand of the Winograd kernel)
@@ -484,7 +507,7 @@ size_t conv3x3_wino_image_bytes(int Cin, int Cout) {
     return (size_t)((Cout + WN_TC - 1) / WN_TC) * (Cin / 64) * 12 * WN_WSLOT;
 }
 
-template <int NW, int ABL = 0>
+template <int NW, int ABL = 0, bool ROWP = false>
 static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
@@ -492,12 +515,12 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     const size_t img = conv3x3_wino_image_bytes(p.Cin, p.Cout);
     if (img >= 0x7fffffffUL) return hipErrorInvalidValue;
     p.w_bytes = (unsigned)img;
-    const int lds = wino_lds_bytes(p.W);
+    const int lds = ROWP ? wino_rowp_lds_bytes() : wino_lds_bytes(p.W);
     static int attr_lds[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (attr_lds[dev] < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((conv3x3_wino_kernel<NW, ABL>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((conv3x3_wino_kernel<NW, ABL, ROWP>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_lds[dev] = 160 * 1024;
     }
@@ -506,15 +529,15 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
-    hipLaunchKernelGGL((conv3x3_wino_kernel<NW, ABL>), dim3(grid), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<NW, ABL, ROWP>), dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
 #ifdef FRP_LAB   // dbg bit 32: the one-wave-per-SIMD configuration (A/B runs in the lab build; 0.7 x the speed of the default)
-    if (p.dbg & 32) return launch_wino_cfg<4>(p, stream);
-    switch ((p.dbg >> 1) & 15) {               // dbg bits 1..4: timing ablations (tools/wino_ablate.py)
+    if ((p.dbg & 32) && wino_super_patch(p.W)) return launch_wino_cfg<4>(p, stream);
+    if (wino_super_patch(p.W)) switch ((p.dbg >> 1) & 15) {               // dbg bits 1..4: timing ablations (tools/wino_ablate.py)
         case 1: return launch_wino_cfg<8, 1>(p, stream);
         case 2: return launch_wino_cfg<8, 2>(p, stream);
         case 4: return launch_wino_cfg<8, 4>(p, stream);
@@ -529,6 +552,10 @@ hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
         default: break;
     }
 #endif
+#ifdef FRP_LAB
+    if (!wino_super_patch(p.W) || (p.dbg & 64)) return launch_wino_cfg<8, 0, true>(p, stream);     // wide maps (dbg bit 64: force, A/B)
+#endif
+    if (!wino_super_patch(p.W)) return hipErrorInvalidValue;
     return launch_wino_cfg<8>(p, stream);
 }
 

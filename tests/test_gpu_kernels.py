@@ -591,7 +591,7 @@ def test_conv_winograd_parity(engine, case):
 
 def test_conv_winograd_rejects_what_it_does_not_cover(engine):
     from frp_amd.native import FrpError
-    for shape, k, stride in (((1, 7, 7, 64), 3, 1), ((1, 8, 8, 32), 3, 1), ((1, 8, 8, 64), 1, 1), ((1, 8, 8, 64), 3, 2), ((1, 8, 64, 64), 3, 1)):
+    for shape, k, stride in (((1, 7, 7, 64), 3, 1), ((1, 8, 8, 32), 3, 1), ((1, 8, 8, 64), 1, 1), ((1, 8, 8, 64), 3, 2), ((1, 8, 63, 64), 3, 1), ((1, 8, 64, 64), 3, 1)):
         x = np.zeros(shape, np.float16)
         w = np.zeros((64, k, k, shape[3]), np.float16)
         with pytest.raises(FrpError):

@@ -17,6 +17,13 @@ SHAPES = [  # name, N, H, W, Cin, Cout, act, flags, res
     ("emb stage 2 conv2 (28x28 128->128, residual)", 320, 28, 28, 128, 128, 0, 0, True),
     ("emb layer3.0.conv1 (28x28 128->256)", 320, 28, 28, 128, 256, 2, 1, False),
     ("emb layer4.0.conv1 (14x14 256->512)", 320, 14, 14, 256, 512, 2, 1, False),
+    # row-patch form (W > 30): the detector's maps at 32 x 1080p, the embedder's 56 x 56
+    ("det 136x240 128->128 (ReLU)", 32, 136, 240, 128, 128, 1, 0, False),
+    ("det 136x240 128->128 (residual + ReLU)", 32, 136, 240, 128, 128, 1, 0, True),
+    ("det 68x120 256->256 (residual + ReLU)", 32, 68, 120, 256, 256, 1, 0, True),
+    ("det 68x120 128->128 (ReLU)", 32, 68, 120, 128, 128, 1, 0, False),
+    ("det 34x60 256->256 (ReLU)", 32, 34, 60, 256, 256, 1, 0, False),
+    ("emb layer2.0.conv1 (56x56 64->128)", 320, 56, 56, 64, 128, 2, 1, False),
 ]
 
 
@@ -28,6 +35,9 @@ def main():
         best = [1e30, 1e30, 1e30]
         for _ in range(3):
             for v, extra in enumerate((0, 0x10000, 0x10000 | (32 << 8))):     # direct, Winograd 2 waves per SIMD, 1 wave per SIMD
+                if v == 2 and W > 30:                                          # (one wave per SIMD exists for the super-patch form only)
+                    best[v] = float("nan")
+                    continue
                 best[v] = min(best[v], eng.conv_bench(N, H, W, Ci, Co, 3, 1, act, fl | extra, res, iters) * 1e3)
         fl_ = 2.0 * N * H * W * 9 * Ci * Co
         for v in range(3):
