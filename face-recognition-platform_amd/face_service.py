@@ -535,18 +535,35 @@ class FaceService:
         can hit several near-duplicate identities), ascending by distance, under "matches"."""
         return self._process_frames_on(self._eng(), self.ENCODINGS.locked(), frames_bgr, max_faces, threshold, det_thresh, all_matches)
 
-    def _process_frames_on(self, eng, guard, frames_bgr, max_faces, threshold, det_thresh, all_matches):
+    def _process_frames_on(self, eng, guard, frames_bgr, max_faces, threshold, det_thresh, all_matches, take_next=None, staged=None):
+        """`take_next` / `staged` (process_stream on a real engine): the overlapped-ingest form - this batch goes to the device
+        through the engine's staging buffer (already there when the previous call staged it), the batch the lane will get
+        next is claimed and its upload started on the copy stream while this batch's kernels run."""
         tol = self.tolerance if threshold is None else min(self.tolerance, threshold)   # camera.py:250
         G = self.ENCODINGS
+        overlapped = take_next is not None and staged is not None
         # The device returns gallery ROW indices; store/delete move rows (swap-remove).  The guard (exclusive for
         # process_frames, shared between the lanes of process_stream) is held over the device call and the
         # row -> name snapshot, so a concurrent delete can neither mis-attribute a face to the identity that was
         # moved into its row nor shrink the table under the lookup.
+        if overlapped:
+            key = id(frames_bgr)
+            if staged.pop("key", None) != key:                         # not staged by the previous call: stage it now
+                eng.upload_frames_async(frames_bgr)
+            eng.swap_frames()
         with guard:
             have_gallery = len(G) > 0
-            out = eng.process_frames(frames_bgr, max_faces=max_faces,
-                                             det_thresh=DET_THRESH if det_thresh is None else det_thresh, nms_iou=NMS_IOU,
-                                             flags=0 if have_gallery else native.FLAG_NO_MATCH)
+            dt = DET_THRESH if det_thresh is None else det_thresh
+            fl = 0 if have_gallery else native.FLAG_NO_MATCH
+            if overlapped:
+                eng.process_resident(max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)       # asynchronous
+                nxt = take_next()
+                if nxt is not None:
+                    eng.upload_frames_async(nxt)                       # copy stream: under this batch's kernels
+                    staged["key"] = id(nxt)
+                out = eng.fetch_results()                              # waits for the pass
+            else:
+                out = eng.process_frames(frames_bgr, max_faces=max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)
             n_gallery = len(G)
             row_names = {int(r): G.name_of_row(int(r)) for r in np.unique(out["match_idx"]) if r >= 0}
             all_d = names = None
@@ -608,8 +625,17 @@ class FaceService:
         if e2 is not None:
             engines.append(e2)
         def on(eng):
-            return lambda frames: self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold, det_thresh, all_matches)
-        return lanes.run_ordered(batches, [on(e) for e in engines])
+            if not all(hasattr(eng, m) for m in ("upload_frames_async", "swap_frames", "process_resident", "fetch_results", "sequence")):
+                return lambda frames, take_next: self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold,
+                                                                         det_thresh, all_matches)
+            staged = {}                         # which batch sits in this lane's staging buffer
+
+            def fn(frames, take_next):
+                with eng.sequence():            # upload -> swap -> process -> fetch of one lane is one uninterrupted sequence
+                    return self._process_frames_on(eng, self.ENCODINGS.reading(), frames, max_faces, threshold, det_thresh, all_matches,
+                                                   take_next, staged)
+            return fn
+        return lanes.run_ordered(batches, [on(e) for e in engines], prefetch=True)
 
     def frame_buffer(self, batch: int, height: int, width: int) -> np.ndarray:
         """A page-locked u8 [batch, height, width, 3] array (owned by the engine, freed with it) for the capture / decode

@@ -25,13 +25,18 @@ import numpy as np
 from . import native
 
 
-def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[[Any], Any]]) -> Iterator[Any]:
+def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], prefetch: bool = False) -> Iterator[Any]:
     """The one in-order, bounded-look-ahead pipeline behind Lanes.run and FaceService.process_stream: `workers[i]` (one
     host thread each) turn items of `batches` into results; results are yielded in submission order; at most
     2 x len(workers) items are taken ahead of the consumer.  An exception of the iterator or of a worker is raised in
     the consumer.  When the consumer abandons the generator (close(), break, an exception in its loop body) every
     worker - also one parked on the look-ahead throttle - leaves after the item it is working on: the throttle's
-    wait tests `exhausted` too (it did not: a consumer slower than the device that stopped early hung in join())."""
+    wait tests `exhausted` too (it did not: a consumer slower than the device that stopped early hung in join()).
+
+    `prefetch=True`: workers are called as fn(item, take_next); `take_next()` - callable once per item, never blocking -
+    claims the item this worker will get NEXT (or None: source dry, throttle full) so that the worker can start moving
+    it to the device while the current item is being processed (FaceService.process_stream: the upload of batch t+1
+    overlaps the kernels of batch t on the same lane)."""
     it = iter(batches)
     n = len(workers)
     if n < 1:
@@ -39,27 +44,48 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[[Any], Any]])
     cv = threading.Condition()
     st = {"next": 0, "yielded": 0, "done": {}, "exhausted": False, "error": None}
 
-    def loop(fn: Callable[[Any], Any]) -> None:
+    def claim(block: bool):
+        """(index, item) of the next source item, or None; call with cv held"""
+        while block and st["next"] - st["yielded"] >= 2 * n and st["error"] is None and not st["exhausted"]:
+            cv.wait()
+        if st["exhausted"] or st["error"] is not None or (not block and st["next"] - st["yielded"] >= 2 * n):
+            return None
+        try:
+            item = next(it)
+        except StopIteration:
+            st["exhausted"] = True
+            cv.notify_all()
+            return None
+        except BaseException as ex:      # the caller's iterator failed: surface it in the consumer
+            st["error"] = ex
+            cv.notify_all()
+            return None
+        t = st["next"]
+        st["next"] += 1
+        return t, item
+
+    def loop(fn: Callable[..., Any]) -> None:
+        ahead = None                     # the item this worker claimed early (prefetch)
         while True:
-            with cv:
-                while st["next"] - st["yielded"] >= 2 * n and st["error"] is None and not st["exhausted"]:
-                    cv.wait()
-                if st["exhausted"] or st["error"] is not None:
+            if ahead is not None:
+                (t, item), ahead = ahead, None
+            else:
+                with cv:
+                    got = claim(True)
+                if got is None:
                     return
-                try:
-                    item = next(it)
-                except StopIteration:
-                    st["exhausted"] = True
-                    cv.notify_all()
-                    return
-                except BaseException as ex:      # the caller's iterator failed: surface it in the consumer
-                    st["error"] = ex
-                    cv.notify_all()
-                    return
-                t = st["next"]
-                st["next"] += 1
+                t, item = got
             try:
-                out = fn(item)
+                if prefetch:
+                    def take_next():
+                        nonlocal ahead
+                        if ahead is None:
+                            with cv:
+                                ahead = claim(False)
+                        return None if ahead is None else ahead[1]
+                    out = fn(item, take_next)
+                else:
+                    out = fn(item)
             except BaseException as ex:
                 with cv:
                     st["error"] = ex

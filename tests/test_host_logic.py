@@ -520,6 +520,56 @@ def test_abandoned_stream_with_full_look_ahead_does_not_deadlock(monkeypatch):
         next(lanes_mod.run_ordered([1], []))
 
 
+def test_run_ordered_prefetch_hands_every_item_to_exactly_one_worker_in_order():
+    """prefetch mode (FaceService.process_stream: the next batch's upload overlaps the running one): a worker may claim
+    its NEXT item while it works; every item is processed once, by the worker that claimed it, results stay in
+    submission order, the look-ahead bound holds, an abandoned stream ends"""
+    import itertools
+    import threading
+    import time
+    from frp_amd import lanes as lanes_mod
+    seen, staged_hits, lock = [], [0], threading.Lock()
+
+    def make(wid):
+        staged = {}
+
+        def fn(item, take_next):
+            t = int(item[0])
+            if staged.pop("t", None) == t:
+                with lock:
+                    staged_hits[0] += 1
+            time.sleep(0.002 if t % 3 else 0.01)
+            nxt = take_next()
+            assert take_next() is nxt or nxt is None                       # a second call returns the same claim
+            if nxt is not None:
+                staged["t"] = int(nxt[0])
+            with lock:
+                seen.append((t, wid))
+            return t * 10
+        return fn
+
+    pulled = []
+
+    def src(n):
+        for t in range(n):
+            pulled.append(t)
+            yield np.array([t])
+    got = []
+    for out in lanes_mod.run_ordered(src(40), [make(0), make(1)], prefetch=True):
+        got.append(out)
+        assert len(pulled) - len(got) <= 4
+    assert got == [t * 10 for t in range(40)]
+    assert sorted(t for t, _ in seen) == list(range(40)) and len({w for _, w in seen}) == 2
+    assert staged_hits[0] >= 20                                            # most items arrived at their worker already staged
+    g = lanes_mod.run_ordered((np.array([t]) for t in itertools.count()), [make(0), make(1)], prefetch=True)
+    assert next(g) == 0
+    time.sleep(0.1)
+    th = threading.Thread(target=g.close, daemon=True)
+    th.start()
+    th.join(10)
+    assert not th.is_alive()
+
+
 def test_gallery_rw_lock_and_mirrors():
     """Gallery host logic for two lanes: updates reach every mirror, mirrors only join an empty gallery, shared readers
     run together while a writer waits for them and keeps later readers out"""
