@@ -481,7 +481,7 @@ def main():
         for e_ in lanes:
             e_.upload_frames(frames)
     # The boundary the reference's callers use (never `value`): FaceService.process_stream from HOST frames (page-locked
-    # capture buffers, the blocking frp_process_frames call per batch) to the per-frame lists of per-face dicts the route hands on
+    # capture buffers, overlapped upload per lane) to the per-frame lists of per-face dicts the route hands on
     # (routes/camera.py:243-259) - name lookup, distance, bucket and threshold included - on the same two lanes, in
     # threshold mode (the service API has no forced-K switch).  Compare with threshold_mode_lanes (engine level, resident).
     svc_line = None
@@ -507,7 +507,7 @@ def main():
         svc_line = {"faces_per_s": round(n_faces_v / dt_v, 1), "frames_per_s": round(n_s * B / dt_v, 1),
                     "ms_per_step": round(dt_v / n_s * 1e3, 3), "steps": n_s,
                     "fraction_of_engine_threshold_mode_lanes": round((n_faces_v / dt_v) / max(1e-9, thr_lanes["faces_per_s"]), 3),
-                    "mode": "FaceService.process_stream: host frames in page-locked capture buffers (FaceService.frame_buffer; upload per batch on the lane's stream), list of per-face dicts out "
+                    "mode": "FaceService.process_stream: host frames in page-locked capture buffers (FaceService.frame_buffer; a lane uploads its next batch on its copy stream under the running batch's kernels), list of per-face dicts out "
                             "(target name, distance, cosine, confidence bucket, match flag, bbox, kps, score, 512-d embedding), 2 lanes, threshold mode"}
         for e_ in lanes:
             e_.upload_frames(frames)
