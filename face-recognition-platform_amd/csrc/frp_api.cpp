@@ -1040,6 +1040,7 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
 int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_t dtype) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
     if (n < 0 || (n > 0 && !emb) || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512]");
     DevBuf fresh;   // new snapshot, swapped in when complete
     if (n > 0) {
@@ -1060,6 +1061,7 @@ int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_
 int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_t d) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
     if (n <= 0 || !dev_f16 || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512] fp16 on the device");
     DevBuf fresh;
     FRPCHK(ensure(h, fresh, (size_t)n * d * 2));
@@ -1104,6 +1106,7 @@ const void* frp_gallery_device_ptr(frp_handle* h) {
 int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
     if (!emb || d != FRP_EMB_DIM || row < 0 || row > h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
     std::vector<float> f;
     FRPCHK(to_f32(h, emb, (size_t)d, dtype, f));
@@ -1128,6 +1131,7 @@ int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t 
 int frp_gallery_remove_row(frp_handle* h, int64_t row) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
+    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
     if (row < 0 || row >= h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
     const int64_t last = h->g_rows - 1;
     if (row != last) {

@@ -619,3 +619,36 @@ def test_embedder_winograd_layers_vs_direct_and_oracle(engine, monkeypatch):
     assert 1 - (wino * direct).sum(1).min() <= 2e-5
     print("1 - cos: winograd vs oracle", 1 - (wino * ref).sum(1).min(), "direct vs oracle", 1 - (direct * ref).sum(1).min(),
           "winograd vs direct", 1 - (wino * direct).sum(1).min())
+
+
+def test_gallery_reserve_commit_zero_copy_import(engine):
+    """frp_gallery_reserve / _commit / _device_ptr (the RCCL all-gather lands in the snapshot the engine reserved,
+    dist.allgather_gallery_into_engine): rows written into the reserved buffer by another producer on the GPU (torch here)
+    become the gallery at commit, a second handle copies its snapshot from the first one's device pointer, and a
+    reservation does not survive another gallery call"""
+    from frp_amd import dist as fdist, native
+    from frp_amd.native import FrpError
+    rng = np.random.default_rng(15)
+    rows = fdist.normalize_rows_f16(rng.standard_normal((777, 512)).astype(np.float32))
+    engine.gallery_set(rng.standard_normal((5, 512)).astype(np.float32))
+    ptr = engine.gallery_reserve(1000)                       # capacity beyond the rows that will be committed
+    assert engine.gallery_size() == 5                        # not visible yet
+    t = torch.as_tensor(fdist._DevicePtr(ptr, 1000, 512), device=torch.device("cuda", 0))
+    t[:777].copy_(torch.from_numpy(rows))
+    torch.cuda.synchronize()
+    engine.gallery_commit(777)
+    assert engine.gallery_size() == 777 and np.array_equal(engine.gallery_get(0, 777), rows)
+    q = rows[[3, 500, 776]].astype(np.float32)
+    idx, cos = engine.match(q)
+    assert idx.tolist() == [3, 500, 776] and np.abs(cos - 1).max() < 2e-3
+    e2 = native.Engine(0)
+    e2.gallery_set_device(engine.gallery_device_ptr(), 777)
+    assert np.array_equal(e2.gallery_get(0, 777), rows)
+    e2.close()
+    engine.gallery_reserve(64)
+    engine.gallery_update_row(0, q[0])                       # any other gallery call discards the reservation
+    with pytest.raises(FrpError):
+        engine.gallery_commit(10)
+    with pytest.raises(FrpError):
+        engine.gallery_commit(5)                             # ... and there is nothing to commit without one
+    engine.gallery_set(np.zeros((0, 512), np.float32))
