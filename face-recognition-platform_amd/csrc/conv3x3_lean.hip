@@ -42,8 +42,12 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // 128-cout configuration (1.0 reads per MFMA).  Two 65 KiB patches are all the LDS holds then, so the patch ring has
 // TWO slots: a row's patch is fired ONE row ahead (during the first two k-steps of the row before it: 9 pieces per wave,
 // 5 + 4), its slot is the running patch parity (a scalar, not a constant), and the counted waits change accordingly.
+//
+// TP = 128, TC = 64 (small maps and small batches: fewer 256 x 128 tiles than CUs): quarter tiles, 32 x 32 per wave, 78 KiB of
+// LDS and <= 128 registers, so TWO workgroups share a CU - four times the tiles on twice the slots.  2 fragment reads per MFMA,
+// which does not matter where a launch is one round of latency-bound k-steps; same k order, bit-identical results.
 template <int TC, int WP, int WC, bool F8, int TP>
-__global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
+__global__ __launch_bounds__(512, TP == 128 ? 4 : 2) void conv3x3_lean_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
     if (p.n_dev) {                             // image count known on the device only (threshold mode)
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
         p.n_ptiles = (p.M + TP - 1) / TP;
     }
     constexpr int NW = 8;
-    constexpr int NXS = TP == 256 ? 3 : 2;    // patch ring slots
+    constexpr int NXS = TP == 512 ? 2 : 3;    // patch ring slots
     constexpr int NQ = TP / 64;               // row groups (of 8 rows) per wave; one more group is shared
     constexpr int XROWS = TP + 8;             // TP/8 + 1 groups of 8 rows; rows 0..TP+1 are read
     constexpr int XSLOT = XROWS * 128;        // 33,792 / 66,560 B (multiples of 256)
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
     constexpr int OFF_W = NXS * XSLOT;
     constexpr int OFF_Z = OFF_W + 3 * WSLOT;  // 256 zero bytes (256-aligned)
     constexpr int OFF_PAR = OFF_Z + 256;
-    static_assert(WP * WC == NW && (WI == 1 || WI == 2) && MP * MC <= 4 && (OFF_Z & 255) == 0 && (TP == 256 || (TP == 512 && WI == 1 && !F8)), "layout");
+    static_assert(WP * WC == NW && (WI == 1 || WI == 2) && MP * MC <= 4 && (OFF_Z & 255) == 0 &&
+                  (TP == 256 || (TP == 128 && WI == 1 && !F8) || (TP == 512 && WI == 1 && !F8)), "layout");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) x_piece(cur, q, r, 0, r);
+            for (int q = 0; q <= NQ; ++q) x_piece(cur, q, r, 0, r);
             w_stage(cur, r, 0, r);
         }
     } else {                                   // two slots: row 0 now, row 1 during row 0's k-steps
@@ -316,7 +321,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
         constexpr int TAP = (KH) * 3 + (KW);                                                                    \
         if (TAP == 0) { if (cb == 0) wait_vmcnt<0>(); else wait_vmcnt<WI + 1>(); }                              \
         else if ((KW) == 0) wait_vmcnt<WI + 1>();                                                               \
-        else wait_vmcnt<WI + 2>();                                                                              \
+        else wait_vmcnt<WI + (NQ == 4 ? 2 : 1)>();          /* = the pieces the previous step issued */           \
+        retire_lds_reads();                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                           \
         _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                          \
             bbase[i] = ((tapmask[i] >> TAP) & 1u) ? (KH) * XSLOT + pv[KW][i] : zv[KW][i];                       \
@@ -329,10 +335,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
         if constexpr (!F8) mfma_group(0);                                                                       \
         if (TAP < 7) w_stage(cur, TAP + 2, cbs, (TAP + 2) % 3); else w_stage(nx, TAP - 7, ncbs, (TAP + 2) % 3); \
         if constexpr (!F8) { read_frags(TAP % 3, KW, 2, 0); mfma_group(1); }                                    \
-        if ((KH) == 0) x_piece(cur, (KW) * 2 < 4 ? (KW) * 2 : 4, 2, cbs, 2);                                    \
-        else x_piece(nx, (KW) * 2 < 4 ? (KW) * 2 : 4, (KH) - 1, ncbs, ((KH) + 2) % 3);                          \
+        /* a row patch is NQ + 1 pieces per wave: 5 spread 2 + 2 + 1 over the row's steps (TP = 256), 3 spread 1 + 1 + 1 (128) */ \
+        if ((KH) == 0) x_piece(cur, NQ == 4 ? ((KW) * 2 < 4 ? (KW) * 2 : 4) : (KW), 2, cbs, 2);                 \
+        else x_piece(nx, NQ == 4 ? ((KW) * 2 < 4 ? (KW) * 2 : 4) : (KW), (KH) - 1, ncbs, ((KH) + 2) % 3);       \
         if constexpr (!F8) { read_frags(TAP % 3, KW, 3, 1); mfma_group(0); }                                    \
-        if ((KW) < 2) {                                                                                         \
+        if (NQ == 4 && (KW) < 2) {                                                                              \
             if ((KH) == 0) x_piece(cur, (KW) * 2 + 1, 2, cbs, 2);                                               \
             else x_piece(nx, (KW) * 2 + 1, (KH) - 1, ncbs, ((KH) + 2) % 3);                                     \
         }                                                                                                       \
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lean_kernel(ConvParams p_in) {
         else if ((KW) == 0) wait_vmcnt<1>();                                                                    \
         else if ((KW) == 1) wait_vmcnt<6>();                                                                    \
         else wait_vmcnt<10>();                                                                                  \
+        retire_lds_reads();                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                           \
         _Pragma("unroll") for (int i = 0; i < MP; ++i)                                                          \
             bbase[i] = ((tapmask[i] >> TAP) & 1u) ? xs + pv[KW][i] : zv[KW][i];                                 \
@@ -436,7 +444,7 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
-    const int lds = (TP == 256 ? 3 : 2) * (TP + 8) * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
+    const int lds = (TP == 512 ? 2 : 3) * (TP + 8) * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
     static bool attr_set[64] = {};
     auto kern = conv3x3_lean_kernel<TC, WP, WC, F8, TP>;
     int dev = 0;
@@ -450,7 +458,9 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
-    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
+    const long slots = (long)ncu * (TP == 128 && !getenv("FRP_Q_ONE") ? 2 : 1);                // persistent: one workgroup per CU (quarter tiles: two)
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    if (grid > 256) p.stamps = nullptr;                                // (the diagnostic stamp buffer holds 256 workgroups)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     return hipGetLastError();
 }
@@ -469,6 +479,12 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
     if (p.flags & FRP_FLAG_F8) {                   // fp8 operands: whole 128-channel rows, 128-cout tiles only
         if ((p.Cin & 127) || !p.wscale) return hipErrorInvalidValue;
         return launch_lean_cfg<128, 4, 2, true, 256>(p, stream);
+    }
+    {                                              // few tiles (small maps, few faces): quarter tiles, two workgroups per CU
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        const long def_tiles = p.Cout > 64 ? (long)((p.M + 255) / 256) * ((p.Cout + 127) / 128) : (long)((p.M + 511) / 512);
+        if (conv_small_m(p, def_tiles, device_cu_count(dev))) return launch_lean_cfg<64, 4, 2, false, 128>(p, stream);
     }
     if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false, 256>(p, stream);
     if (p.dbg & 128) return launch_lean_cfg<64, 8, 1, false, 256>(p, stream);      // A/B: the 256-pixel tile (1.5 reads per MFMA)

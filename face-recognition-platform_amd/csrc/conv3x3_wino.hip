@@ -434,6 +434,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         if (T < 9) w_stage(cur.wbase, cb * 12 + T + 3, (T + 3) & 3); else w_stage(nxw, nxst + T - 9, (T + 3) & 3);     \
         mfma_f(1, vcur[1]);                                                                                            \
         mfma_f(2, vcur[2]);                                                                                            \
+        /* write after read (conv_common.h: retire_lds_reads): every fragment read issued so far - the last ones of weight  \
+           slot T & 3 among them, old by now - has returned before the reads of the NEXT sub-step's operands go out; those  \
+           are the only ones in flight at the next barrier, and they and the rest of slot (T + 1) & 3's reads return at this  \
+           point of sub-step T + 1, a barrier before sub-step T + 2 restages that slot.  (In front of the barrier the wait cost  \
+           1.7 % of the embedder: it held the prefetched operands of the first MFMAs back.) */                          \
+        retire_lds_reads();                                                                                            \
         if (pf) { read_u((T + 1) & 3, 0); read_u((T + 1) & 3, 1); }                                                    \
         mfma_f(3, vcur[3]);                                                                                            \
         if (pf) transform_raw();                                                                                       \

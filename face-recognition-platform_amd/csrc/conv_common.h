@@ -56,6 +56,16 @@ static int device_cu_count(int dev) {
     return n_cu[dev];
 }
 
+// Small-M rule shared by the conv launchers: quarter tiles (128 pixels x 64 couts, two workgroups per CU) when the default
+// tiling would leave at least half of the CUs without a tile - small pyramid scales, a handful of faces, single images.
+// With the image count on the device (n_dev) the decision - like the grid - goes by the capacity.  Same k order: bit-identical
+// to the default tiles of the same kernel family.
+static inline bool conv_small_m(const ConvParams& p, long default_tiles, int ncu) {
+    if (p.small_m < 0 || p.ksplit != 1 || p.out2 || (p.flags & (FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_OUT_F32))) return false;
+    if (p.small_m > 0) return true;
+    return ncu > 0 && default_tiles * 2 <= ncu;
+}
+
 // q = m / d, r = m % d for 0 <= m < 2^24 via a float reciprocal and one correction step
 // (an integer division costs ~40 instructions; the prologue needs two per pixel row)
 __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
@@ -340,6 +350,17 @@ __device__ __forceinline__ void conv_residual_loads(const ConvParams& p, uint4 (
 }
 
 __device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// In front of a k-step's barrier: every fragment read of the step before must have RETURNED before another wave, released by
+// this barrier, fires the LDS-DMA that restages the ring slot it read (write after read).  The source order alone does not
+// give that: the compiler sinks the last MFMA group of a step - and with it the lgkmcnt wait that retires its reads - below
+// the barrier, and under LDS load (two workgroups per CU, 2 reads per MFMA: the quarter-tile configurations) a read issued
+// before the barrier lost the race against a DMA from L2 issued after it: one wave with one stale 8-row piece, one launch in
+// four (tools/quarter_check.py).  FRP_WAR_RELAXED builds leave the wait out (A/B of its cost).
+__device__ __forceinline__ void retire_lds_reads() {
+#ifndef FRP_WAR_RELAXED
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

@@ -41,7 +41,7 @@
 namespace frp {
 
 template <int TP, int TC, int WP, int WC, int NS, int NW, bool SMALL>
-__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p_in) {
+__global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ConvParams p = p_in;
     if (p.n_dev) {                             // image count known on the device only (threshold mode)
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvParams p_in) 
             if (NS == 3 && issued - consumed >= 2 && !(ks == 0 && ct != t0)) wait_vmcnt<(NS == 3 ? LPS : 0)>(); else wait_vmcnt<0>();
             // every wave's DMA of this stage is in LDS, and every wave is done reading the previous
             // stage, whose ring slot the next issue goes into
+            retire_lds_reads();
             __builtin_amdgcn_s_barrier();
             const unsigned char* xs = smem + buf * STAGE;
             const unsigned char* ws = xs + XB;
@@ -431,6 +432,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     // contiguous range of tiles
     const long slots = (long)ncu * (lds <= 80 * 1024 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    if (grid > 256) p.stamps = nullptr;                                // (the diagnostic stamp buffer holds 256 workgroups)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
@@ -478,6 +480,13 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         if (!conv3x3_rows_eligible(p) || (p.Cin & 127) || !p.wscale || !(p.in_scale > 0.f)) return hipErrorInvalidValue;
         return launch_conv3x3_lean(p, stream);
     }
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    const int ncu_ = device_cu_count(dev_);
+    // few 256 x 128 tiles (small pyramid scales, a handful of faces): quarter tiles, two workgroups per CU (conv_small_m)
+    const bool few = conv_small_m(p, (long)((p.M + 255) / 256) * ((p.Cout + 127) / 128), ncu_);
+    // (a caller that hands over the Winograd image has chosen the kernel FAMILY - frp_api.cpp: run_embed, by the slots of the
+    // call -; the tile count of a single launch does not overrule it: the families differ in the last bits)
     if (p.wino_w && !(p.dbg & 1) && conv3x3_wino_eligible(p)) {      // Winograd F(2,3) along the rows: 1.5 x fewer MFMAs
         p.w = p.wino_w;
         return launch_conv3x3_wino(p, stream);
@@ -493,6 +502,7 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     //               rings) were 20-25 % slower; a 128x64 per-wave tile does not fit 256 VGPRs.
     //   Cout <= 64: 256 x 64, 8 waves (32x64 each), 3-slot ring (a 512 x 64 tile with 64x64 per wave
     //               measured 10 % slower, two co-resident 4-wave 128 x 64 groups 0-4 % slower).
+    if (!small && few) return launch_cfg<128, 64, 4, 2, 3, 8, false>(p, stream);
     if (p.Cout > 64)
         return small ? launch_cfg<256, 128, 4, 2, 3, 8, true>(p, stream) : launch_cfg<256, 128, 4, 2, 3, 8, false>(p, stream);
     return small ? launch_cfg<256, 64, 8, 1, 3, 8, true>(p, stream) : launch_cfg<256, 64, 8, 1, 3, 8, false>(p, stream);

@@ -303,14 +303,19 @@ bool stem12_fusable(const Net& net) {
 // `n_dev`: the number of images that really exist lives in device memory (`batch` is then the capacity the buffers were
 // planned for): every kernel derives its tile count from it.  The flop counters are charged for `batch` images and
 // corrected by the caller once the count is known.
+// `allow_wino` false: the direct kernels also where a Winograd weight image exists (calls of few faces, run_embed).
 int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr,
-            const int32_t* n_dev = nullptr) {
+            const int32_t* n_dev = nullptr, bool allow_wino = true) {
     // dims are re-derived while walking (physical buffers are reused by several tensors)
     std::vector<TensorDims> d(net.n_bufs);
     d[net.in_buf] = {H, W, net.in_ch, false};
     const char* wbase = (const char*)h->wdata.p;
     bool first = true;
     size_t skip = 0;
+    // tile class of the conv launches (conv_common.h: conv_small_m): FRP_SMALL_M=0 never quarter tiles, =1 always, unset: by
+    // the tile count of each launch (A/B runs, tests that pin a kernel family)
+    const char* sm_env = getenv("FRP_SMALL_M");
+    const int small_m = !sm_env ? 0 : (sm_env[0] == '0' ? -1 : 1);
     // both detector stems in one kernel (the stem1 map never reaches HBM); FRP_NO_FUSED_STEM12=1 keeps
     // stem1 (fused with the u8 normalisation) and stem2 (generic conv) apart for A/B runs
     if (stem && stem12_fusable(net) && (stem->Hc % 4) == 0 && (stem->Wc % 4) == 0 && !getenv("FRP_NO_FUSED_STEM12")) {
@@ -384,9 +389,10 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.KS = op.ksize; p.stride = op.stride; p.act = op.act;
         p.n_dev = n_dev;
         p.n_cu = h->n_cu;
+        p.small_m = small_m;
         {
             const size_t oi = (size_t)(&op - net.ops.data());
-            if (oi < net.wino_off.size() && net.wino_off[oi] >= 0) p.wino_w = (const _Float16*)(wbase + net.wino_off[oi]);
+            if (allow_wino && oi < net.wino_off.size() && net.wino_off[oi] >= 0) p.wino_w = (const _Float16*)(wbase + net.wino_off[oi]);
         }
         p.flags = op.flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
         if (op.flags & FRP_FLAG_RES_UP2) { p.Hr = d[op.res_buf].h; p.Wr = d[op.res_buf].w; }
@@ -587,9 +593,20 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
 }
 
 // chips for n faces are in emb.bufs[in]; run embedder + l2norm (+ fp16 copy for the matcher)
-int run_embed(frp_handle* h, int n, const int32_t* n_dev = nullptr) {
+// Kernel family of an embedder pass.  The Winograd kernel (256 x 128 tiles only) pays from about a hundred faces up; below,
+// the direct kernels in quarter tiles are up to 2.6 x faster (tools/small_m_probe.py).  The two families differ in the last
+// bits (1 - cos 1.6e-6), so the choice is made ONCE per call, from a count that does not depend on what the detector
+// found: `family_count` = the slots of the call (B x K of a process call, whether the face count stays on the device or
+// not; the faces handed to the embed / finish calls).  Within a family every tile size gives the same bits, so a face's
+// embedding depends on the call's slot count being above or below FRP_WINO_MIN_FACES and on nothing else in the batch.
+#define FRP_WINO_MIN_FACES 65
+int run_embed(frp_handle* h, int n, const int32_t* n_dev = nullptr, int family_count = -1) {
     if (n <= 0) return FRP_OK;
-    FRPCHK(run_net(h, h->emb, n, FRP_CHIP, FRP_CHIP, &h->ctr.emb_conv_flops, &h->ctr.emb_conv_launches, nullptr, n_dev));
+    if (family_count < 0) family_count = n;
+    const char* wm = getenv("FRP_WINO_MIN_FACES");               // A/B runs and tests that pin the family
+    const int wino_min = wm ? atoi(wm) : FRP_WINO_MIN_FACES;
+    FRPCHK(run_net(h, h->emb, n, FRP_CHIP, FRP_CHIP, &h->ctr.emb_conv_flops, &h->ctr.emb_conv_launches, nullptr, n_dev,
+                   family_count >= wino_min));
     rec(h, EV_EMB);
     const int mpad = round_up(n, 32);
     FRPCHK(ensure(h, h->q16, (size_t)mpad * FRP_EMB_DIM * 2));
@@ -676,7 +693,7 @@ int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
         hipError_t e = launch_align(ap, h->stream);
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("align: ") + hipGetErrorString(e));
         rec(h, EV_ALIGN);
-        FRPCHK(run_embed(h, n, n_dev));
+        FRPCHK(run_embed(h, n, n_dev, n_known >= 0 ? n_known : B * K));
         if (!(flags & FRP_FLAG_NO_MATCH) && h->g_rows > 0) {
             FRPCHK(run_match(h, n, nullptr, n_dev));
             h->last_matched = true;
@@ -1605,6 +1622,8 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
             p.dbg = (flags >> 8) & 0xff;      // kernel A/B switches (tests: 1 = generic kernel instead of the row-patch one)
+            // flags bit 17 / 18: quarter tiles always / never (default: by the tile count, conv_common.h: conv_small_m)
+            p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || want_wino) ? -1 : 0;
             p.Hr = res_h; p.Wr = res_w;
             if (want_wino) p.wino_w = (const _Float16*)dwino.p;
             e = launch_conv(p, h->stream);
@@ -1711,6 +1730,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
             if (with_res) p.out2 = nullptr;
         }
         p.dbg = (flags >> 8) & 0xff;
+        p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
         if ((flags & 0x10000) && conv3x3_wino_shape_ok(W, Cin, ksize, stride)) {     // Winograd kernel: a random weight image (timing only)
             const size_t ib = conv3x3_wino_image_bytes(Cin, Cout);

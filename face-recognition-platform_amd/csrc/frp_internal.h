@@ -42,6 +42,8 @@ struct ConvParams {
     int n_cu;               // compute units (input of the device-side split-K choice)
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
     int dbg;                // A/B switch (tests, conv_bench): 1 = generic kernel also for row-patch shapes
+    int small_m;            // quarter tiles (128 pixels x 64 couts, two workgroups per CU): 0 = when the default tiling leaves half
+                            // of the CUs idle (conv_common.h: conv_small_m), 1 = always, -1 = never (tests, A/B runs)
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
     unsigned x_bytes, w_bytes;   // buffer-descriptor sizes (each < 2 GiB)

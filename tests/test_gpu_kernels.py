@@ -69,8 +69,15 @@ CONV_CASES = [
 ]
 
 
+# Tile class of a conv launch (conv_common.h: conv_small_m): by default the launcher takes quarter tiles (128 pixels x 64 couts,
+# two workgroups per CU) when the default tiling would leave half of the CUs idle - which is every case of this list.  The
+# tests therefore name the class: bit 18 = default tiles (what the 32 x 1080p / 320-face workloads run), bit 17 = quarter tiles.
+TILES_DEFAULT, TILES_QUARTER = 0x40000, 0x20000
+
+
+@pytest.mark.parametrize("tiles", [TILES_DEFAULT, TILES_QUARTER], ids=["default-tiles", "quarter-tiles"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_parity(engine, case):
+def test_conv_parity(engine, case, tiles):
     N, H, W, Cin, Cout, k, stride, act, has_res, flags = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
@@ -82,7 +89,7 @@ def test_conv_parity(engine, case):
     res = None
     if has_res:
         res = rng.standard_normal((N, Ho // 2, Wo // 2, Cout) if flags & 4 else (N, Ho, Wo, Cout)).astype(np.float16)
-    out = engine.conv2d(x, w, bias, stride=stride, act=act, slope=slope, res=res, flags=flags)
+    out = engine.conv2d(x, w, bias, stride=stride, act=act, slope=slope, res=res, flags=flags | tiles)
     ref = _conv_ref(x, w, bias, stride, act, slope, res, flags)
     assert out.shape == ref.shape
     # fp32 accumulate: error is the fp16 output rounding (rel 2^-11) + summation order
@@ -101,9 +108,45 @@ def test_conv_row_patch_kernel_equals_generic_kernel(engine, case):
     bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
     slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
     res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
-    a = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags)
-    b = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | (1 << 8))
+    a = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT)
+    b = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT | (1 << 8))
     assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+# cases the quarter-tile configurations cover with the k order of the default tiles (fp16 output, no split-K)
+QUARTER_CASES = [c for c in CONV_CASES if c[3] % 64 == 0 and not (c[9] & 2)] + [
+    (36, 14, 14, 256, 256, 3, 1, 2, True, 1),    # 36 faces at IResNet stage 3 (config 4's operating point): 56 default tiles
+    (36, 28, 28, 128, 256, 3, 2, 0, True, 0),    # ... its stride-2 conv with the shortcut as residual
+    (4, 34, 60, 128, 32, 3, 1, 0, False, 0),     # detector head at pyramid scale 0.25
+    (1, 14, 14, 256, 512, 1, 2, 0, False, 0),    # one face: 1x1 stride-2 shortcut
+    (9, 7, 7, 512, 512, 3, 1, 2, True, 1),       # stage 4, 4 channel blocks... 8 of them, 8 cout tiles
+]
+
+
+@pytest.mark.parametrize("case", QUARTER_CASES)
+def test_conv_quarter_tiles_equal_default_tiles(engine, case):
+    """Quarter tiles (small maps / few faces) keep the k order of the default tiles -> identical bits, in the row-patch
+    kernel and in the generic one; and the automatic choice is one of the two."""
+    N, H, W, Cin, Cout, k, stride, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 2)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float16)
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = None
+    if has_res:
+        res = rng.standard_normal((N, Ho // 2, Wo // 2, Cout) if flags & 4 else (N, Ho, Wo, Cout)).astype(np.float16)
+    kw = dict(stride=stride, act=act, slope=slope, res=res)
+    big = engine.conv2d(x, w, bias, flags=flags | TILES_DEFAULT, **kw)
+    quarter = engine.conv2d(x, w, bias, flags=flags | TILES_QUARTER, **kw)
+    auto = engine.conv2d(x, w, bias, flags=flags, **kw)
+    assert np.array_equal(big.view(np.uint16), quarter.view(np.uint16))
+    assert np.array_equal(big.view(np.uint16), auto.view(np.uint16))
+    if k == 3 and stride == 1:      # ... and the generic kernel's quarter tiles
+        gq = engine.conv2d(x, w, bias, flags=flags | TILES_QUARTER | (1 << 8), **kw)
+        assert np.array_equal(big.view(np.uint16), gq.view(np.uint16))
 
 
 def test_conv_rejects_unsupported_shape(engine):
@@ -484,20 +527,29 @@ def test_match_topk_rejects_bad_k(engine):
         engine.match(np.ones((1, 512), np.float32), topk=65)
 
 
-def test_embedder_large_batch_equals_small_batch_and_oracle(engine):
+def test_embedder_large_batch_equals_small_batch_and_oracle(engine, monkeypatch):
     """IResNet-100 on 330 faces (every stage spans several tiles per workgroup: XCD-interleaved walk, ragged last
-    tiles) gives, face by face, the result of a 3-face call up to the fp32 summation order of the FC (its split-K
-    factor depends on the batch), which the fp32 oracle confirms"""
+    tiles) gives, face by face, the result of a 3-face call on the same tile class up to the fp32 summation order of the
+    FC (its split-K factor depends on the batch), which the fp32 oracle confirms.  Left to itself a call of fewer than 65
+    faces takes the DIRECT kernels also where the big batch runs the Winograd kernel (28 x 28, 14 x 14): the two
+    families agree to 1 - cos <= 2e-5 (measured 1.6e-6), three orders of magnitude inside the 1e-3 bar."""
     rng = np.random.default_rng(404)
     chips = rng.integers(0, 256, size=(330, 112, 112, 3), dtype=np.uint8)
     raw, blob = get_raw_and_blob((1, 1, 1, 1), (3, 13, 30, 3))
     engine.load_weights(blob)
     big = engine.embed_aligned(chips)
     pick = [0, 151, 329]
+    monkeypatch.setenv("FRP_WINO_MIN_FACES", "1")                 # the big batch's kernel family for the three faces
     small = engine.embed_aligned(chips[pick])
+    monkeypatch.delenv("FRP_WINO_MIN_FACES")
     assert np.abs(big[pick] - small).max() < 1e-6
+    few = engine.embed_aligned(chips[pick])                       # the default for three faces: direct kernels, quarter tiles
+    sixty = engine.embed_aligned(chips[:64])                      # ... as for any call below FRP_WINO_MIN_FACES = 65 slots,
+    assert np.abs(sixty[pick[0]] - few[0]).max() < 1e-6           # whatever tile sizes its layers take
+    assert not np.array_equal(few, small)
+    assert 1 - (few * small).sum(1).min() <= 2e-5
     ref = onet.emb_forward(raw, onet.emb_blob(chips[pick]))
-    assert (small * ref).sum(1).min() > 1 - 1e-3
+    assert (small * ref).sum(1).min() > 1 - 1e-3 and (few * ref).sum(1).min() > 1 - 1e-3
     assert np.abs(np.linalg.norm(big, axis=1) - 1).max() < 1e-4
 
 
@@ -577,7 +629,7 @@ def test_conv_winograd_parity(engine, case):
     bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
     slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
     res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
-    direct = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags)
+    direct = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT)
     wino = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | 0x10000)
     ref = _conv_ref(x, w, bias, 1, act, slope, res, flags)
     scale = max(1.0, float(np.abs(ref).max()))
@@ -607,6 +659,9 @@ def test_embedder_winograd_layers_vs_direct_and_oracle(engine, monkeypatch):
     raw, blob = get_raw_and_blob((1, 1, 1, 1), (3, 13, 30, 3))
     engine.load_weights(blob)
     engine.reset_counters()
+    # the kernel family and tile class of big batches (five chips alone take the direct kernels in quarter tiles)
+    monkeypatch.setenv("FRP_WINO_MIN_FACES", "1")
+    monkeypatch.setenv("FRP_SMALL_M", "0")
     wino = engine.embed_aligned(chips)
     monkeypatch.setenv("FRP_NO_WINO", "1")
     engine.load_weights(blob)
@@ -614,6 +669,16 @@ def test_embedder_winograd_layers_vs_direct_and_oracle(engine, monkeypatch):
     monkeypatch.delenv("FRP_NO_WINO")
     engine.load_weights(blob)
     assert not np.array_equal(wino, direct)                       # the two paths really are different kernels
+    # few faces: quarter tiles of the DIRECT kernels (same k order as their default tiles) - bit for bit the direct result
+    monkeypatch.delenv("FRP_SMALL_M")
+    monkeypatch.delenv("FRP_WINO_MIN_FACES")
+    few = engine.embed_aligned(chips)
+    assert np.array_equal(few, direct)
+    monkeypatch.setenv("FRP_SMALL_M", "1")
+    assert np.array_equal(engine.embed_aligned(chips), direct)
+    monkeypatch.setenv("FRP_SMALL_M", "0")                        # direct family, default tiles
+    assert np.array_equal(engine.embed_aligned(chips), direct)
+    monkeypatch.delenv("FRP_SMALL_M")
     ref = onet.emb_forward(raw, onet.emb_blob(chips))
     assert (wino * ref).sum(1).min() > 1 - 1e-3 and (direct * ref).sum(1).min() > 1 - 1e-3
     assert 1 - (wino * direct).sum(1).min() <= 2e-5
