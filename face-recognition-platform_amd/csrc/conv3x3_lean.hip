@@ -46,7 +46,11 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // TP = 128, TC = 64 (small maps and small batches: fewer 256 x 128 tiles than CUs): quarter tiles, 32 x 32 per wave, 78 KiB of
 // LDS and <= 128 registers, so TWO workgroups share a CU - four times the tiles on twice the slots.  2 fragment reads per MFMA,
 // which does not matter where a launch is one round of latency-bound k-steps; same k order, bit-identical results.
-template <int TC, int WP, int WC, bool F8, int TP>
+//
+// TCU (used couts of the tile, default TC): the detector's head outputs have 30 (32) couts - half of a 64-cout tile would
+// multiply zero rows.  TCU = 32 keeps the 64-row weight stage in LDS (rows beyond Cout arrive as zeros by the range check,
+// no HBM traffic) and drops the second 32-cout MFMA block: half the MFMAs, 3 instead of 4 fragment reads per sub-step.
+template <int TC, int WP, int WC, bool F8, int TP, int TCU = TC>
 __global__ __launch_bounds__(512, TP == 128 ? 4 : 2) void conv3x3_lean_kernel(ConvParams p_in) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(512, TP == 128 ? 4 : 2) void conv3x3_lean_kernel(Co
     constexpr int XSLOT = XROWS * 128;        // 33,792 / 66,560 B (multiples of 256)
     constexpr int WSLOT = TC * 128;
     constexpr int WI = TC / 8 / NW;           // weight DMA pieces per wave per k-step (2 or 1)
-    constexpr int MP = TP / WP / 32, MC = TC / WC / 32;
+    constexpr int MP = TP / WP / 32, MC = TCU / WC / 32;
+    static_assert(TCU <= TC && TCU % (WC * 32) == 0, "used couts: whole 32-cout blocks per wave");
     constexpr int OFF_W = NXS * XSLOT;
     constexpr int OFF_Z = OFF_W + 3 * WSLOT;  // 256 zero bytes (256-aligned)
     constexpr int OFF_PAR = OFF_Z + 256;
@@ -439,14 +444,14 @@ __global__ __launch_bounds__(512, TP == 128 ? 4 : 2) void conv3x3_lean_kernel(Co
     stamp(p.stamps, 6);
 }
 
-template <int TC, int WP, int WC, bool F8, int TP>
+template <int TC, int WP, int WC, bool F8, int TP, int TCU = TC>
 static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     p.n_ptiles = (p.M + TP - 1) / TP;
     p.n_ctiles = (p.Cout + TC - 1) / TC;
     const int lds = (TP == 512 ? 2 : 3) * (TP + 8) * 128 + 3 * TC * 128 + 256 + 11 * TC * 4;
     static bool attr_set[64] = {};
-    auto kern = conv3x3_lean_kernel<TC, WP, WC, F8, TP>;
+    auto kern = conv3x3_lean_kernel<TC, WP, WC, F8, TP, TCU>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -488,6 +493,7 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
     }
     if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false, 256>(p, stream);
     if (p.dbg & 128) return launch_lean_cfg<64, 8, 1, false, 256>(p, stream);      // A/B: the 256-pixel tile (1.5 reads per MFMA)
+    if (p.Cout <= 32 && !(p.dbg & 64)) return launch_lean_cfg<64, 8, 1, false, 512, 32>(p, stream);   // head outputs (dbg 64: A/B, all 64 rows)
     return launch_lean_cfg<64, 8, 1, false, 512>(p, stream);
 }
 

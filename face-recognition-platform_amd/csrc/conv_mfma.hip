@@ -92,6 +92,8 @@ __global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(C
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    // K-concat: after the 9 * cpt (tap, channel block) stages of a tile come cpt2 stages of tensor x2 at the centre tap
+    const __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x), 0, p.x2 ? p.x2_bytes : 0u, 0x00020000);
 
     // ---------------- DMA lane state of the ISSUE cursor (it runs PRE stages ahead of the MFMAs
     // and crosses into the next tile while the current one is still being multiplied).
@@ -160,13 +162,23 @@ __global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(C
     int st_tapoff = 0;
     unsigned st_bit = 0, st_wadd = 0;
     bool st_kin = true;
+    bool st_seg2 = false;                     // the prepared stage belongs to the second K segment (tensor x2)
     auto prep_stage = [&]() {
         const int ks = iks_base + iks;
         if constexpr (!SMALL) {
-            st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
-            st_bit = 1u << (kh * 3 + kw);
-            st_wadd = (unsigned)(((kh * p.KS + kw) * cpt + cb) << 7);
-            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cb; } }
+            if (cb < cpt) {
+                st_seg2 = false;
+                st_tapoff = ((kh * p.W + kw) * p.Cin + (cb << 6) + lchunk * 8) * 2;
+                st_bit = 1u << (kh * 3 + kw);
+                st_wadd = (unsigned)(((kh * p.KS + kw) * cpt + cb) << 7);
+                if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cb; } }
+            } else {                          // K-concat: channel block cb - cpt of x2, one pixel down and right of the window's corner
+                st_seg2 = true;
+                st_tapoff = ((p.W + 1) * p.Cin2 + ((cb - cpt) << 6) + lchunk * 8) * 2;
+                st_bit = 1u << 4;
+                st_wadd = (unsigned)((p.KS * p.KS * cpt + (cb - cpt)) << 7);
+                ++cb;
+            }
         } else {
             const int kg = (ks << 6) + lchunk * 8;
             const int tap = kg >> p.cin_shift;
@@ -180,7 +192,11 @@ __global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(C
             st_wadd = (unsigned)(ks << 7);
         }
     };
-    auto x_off = [&](int i) -> unsigned { return (tapmask[i] & st_bit) ? (unsigned)(xoff[i] + st_tapoff) : CONV_OOB; };
+    // (second segment: the window corner's byte offset in x2 = that in x scaled by Cin2 / Cin - exact, offsets are multiples of 2 Cin)
+    auto x_off = [&](int i) -> unsigned {
+        const int base = (!SMALL && st_seg2) ? (xoff[i] >> p.x2_shift) : xoff[i];
+        return (tapmask[i] & st_bit) ? (unsigned)(base + st_tapoff) : CONV_OOB;
+    };
     auto w_off = [&](int i) -> unsigned { return (st_kin && woff[i] != CONV_OOB) ? woff[i] + st_wadd : CONV_OOB; };
     // after all pieces of the prepared stage are fired: advance the cursor
     auto advance_issue = [&]() {
@@ -196,8 +212,10 @@ __global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(C
         if constexpr ((j) < LPS) {                                                                      \
             constexpr int jo_ = (j) < WI ? (j) + XI : (j) - WI;   /* weight pieces first: +2 % */            \
             unsigned char* base_ = smem + (bufv) * STAGE;                                               \
-            if constexpr (jo_ < XI)                                                                     \
-                dma16(xrsrc, base_ + (jo_ * NW + wave) * 1024, x_off(jo_ < XI ? jo_ : 0));              \
+            if constexpr (jo_ < XI) {                                                                   \
+                if (!SMALL && st_seg2) dma16(x2rsrc, base_ + (jo_ * NW + wave) * 1024, x_off(jo_ < XI ? jo_ : 0)); \
+                else dma16(xrsrc, base_ + (jo_ * NW + wave) * 1024, x_off(jo_ < XI ? jo_ : 0));         \
+            }                                                                                           \
             else                                                                                        \
                 dma16(wrsrc, base_ + XB + ((jo_ - XI) * NW + wave) * 1024, w_off(jo_ >= XI && jo_ < LPS ? jo_ - XI : 0)); \
         }                                                                                               \
@@ -450,6 +468,18 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if (M <= 0 || M > 0x7fffffffL) return hipErrorInvalidValue;
     p.M = (int)M;
     p.Ktot = p.KS * p.KS * p.Cin;
+    p.x2_bytes = 0;
+    p.x2_shift = 0;
+    if (p.x2) {                                  // K-concat: generic kernel, whole channel blocks, plain fp16 epilogue input
+        if (p.KS != 3 || (p.Cin & 63) || p.Cin2 <= 0 || (p.Cin2 & 63) || !(p.Cin == p.Cin2 || p.Cin == 2 * p.Cin2) || p.ksplit > 1 ||
+            (p.flags & (FRP_FLAG_F8 | FRP_FLAG_BORDER_BIAS)) || p.wino_w)
+            return hipErrorInvalidValue;
+        const long x2b = (long)p.N * p.H * p.W * p.Cin2 * 2;
+        if (x2b >= 0x7fffffffL) return hipErrorInvalidValue;
+        p.x2_bytes = (unsigned)x2b;
+        p.x2_shift = p.Cin == p.Cin2 ? 0 : 1;
+        p.Ktot += p.Cin2;
+    }
     p.nk = (p.Ktot + 63) / 64;
     if (p.ksplit < 0 && !(p.n_dev && (p.flags & FRP_FLAG_OUT_F32) && !p.res && !(p.Cin & 63))) return hipErrorInvalidValue;
     if (p.ksplit == 0) p.ksplit = 1;
@@ -487,14 +517,14 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     const bool few = conv_small_m(p, (long)((p.M + 255) / 256) * ((p.Cout + 127) / 128), ncu_);
     // (a caller that hands over the Winograd image has chosen the kernel FAMILY - frp_api.cpp: run_embed, by the slots of the
     // call -; the tile count of a single launch does not overrule it: the families differ in the last bits)
-    if (p.wino_w && !(p.dbg & 1) && conv3x3_wino_eligible(p)) {      // Winograd F(2,3) along the rows: 1.5 x fewer MFMAs
+    if (p.wino_w && !p.x2 && !(p.dbg & 1) && conv3x3_wino_eligible(p)) {      // Winograd F(2,3) along the rows: 1.5 x fewer MFMAs
         p.w = p.wino_w;
         return launch_conv3x3_wino(p, stream);
     }
 #ifdef FRP_LAB   // lab build: dbg bits select the first-generation kernel and its timing ablations (conv3x3_rows.hip)
-    if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
+    if (!(p.dbg & 1) && !p.x2 && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);
 #else
-    if (!(p.dbg & 1) && conv3x3_rows_eligible(p)) return launch_conv3x3_lean(p, stream);
+    if (!(p.dbg & 1) && !p.x2 && conv3x3_rows_eligible(p)) return launch_conv3x3_lean(p, stream);
 #endif
     // Tile selection (measured on MI355X, tools/conv_bench.py):
     //   Cout > 64 : 256 pixels x 128 couts, 8 waves (64x64 each), 3-slot ring (144 KiB, one

@@ -41,6 +41,10 @@ struct Net {
     std::vector<DevBuf> bufs;
     std::vector<TensorDims> dims;   // per physical buffer, for the last planned shape
     std::vector<int64_t> wino_off;  // per op: byte offset of its Winograd weight image in the data section, or -1
+    // K-concat (conv_mfma.hip): a block's 1x1 stride-s shortcut conv folded into its 3x3 stride-s conv as a second K segment
+    std::vector<int> kc_skip;       // per op: 1 = a shortcut conv that its consumer computes (not launched)
+    std::vector<int> kc_src;        // per op: index of the shortcut op folded into this conv, or -1
+    std::vector<int64_t> kc_w_off, kc_bias_off;   // per consumer op: concatenated weights [Cout][9 Cin + Cin2] / summed bias [Cout]
 };
 
 enum { EV_START = 0, EV_H2D, EV_PRE, EV_DET, EV_DEC, EV_ALIGN, EV_EMB, EV_L2, EV_MATCH, EV_D2H, EV_COUNT };
@@ -378,6 +382,16 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         first = false;
         TensorDims in = d[op.in_buf];
         if (op.flags & FRP_FLAG_FLATTEN) in = {1, 1, in.h * in.w * in.c, false};
+        const size_t opi = (size_t)(&op - net.ops.data());
+        if (opi < net.kc_skip.size() && net.kc_skip[opi]) {        // a shortcut conv its consumer computes (K-concat): FLOPs charged here
+            TensorDims o;
+            o.h = (in.h - 1) / op.stride + 1;
+            o.w = (in.w - 1) / op.stride + 1;
+            o.c = op.cout;
+            d[op.out_buf] = o;
+            *flops += 2.0 * batch * o.h * o.w * (double)op.cin * op.cout;
+            continue;
+        }
         ConvParams p{};
         p.x = (const _Float16*)net.bufs[op.in_buf].p;
         p.w = (const _Float16*)(wbase + op.w_off);
@@ -402,6 +416,14 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
             p.flags |= FRP_FLAG_F8;
             p.wscale = (const float*)(wbase + op.w_off + (welems + 15) / 16 * 16);
             p.in_scale = op.in_scale;
+        }
+        if (opi < net.kc_src.size() && net.kc_src[opi] >= 0) {      // K-concat: the block's shortcut conv rides in this conv's k-loop
+            const frp_conv_op& sc = net.ops[net.kc_src[opi]];
+            p.x2 = (const _Float16*)net.bufs[sc.in_buf].p;
+            p.Cin2 = sc.cin;
+            p.w = (const _Float16*)(wbase + net.kc_w_off[opi]);
+            p.bias = (const float*)(wbase + net.kc_bias_off[opi]);
+            p.res = nullptr;
         }
         if (op.flags & FRP_OPFLAG_OUT_FP8) p.flags |= FRP_FLAG_OUT_FP8;
         if (op.out2_buf >= 0) p.out2 = net.bufs[op.out2_buf].p;
@@ -1044,6 +1066,63 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
         }
         data = expanded.data();
         data_bytes = expanded.size();
+    }
+    // K-concat plans (both networks; FRP_NO_KCONCAT=1: every op as written in the blob)
+    for (Net* net : {&h->det, &h->emb}) {
+        const size_t n_ops = net->ops.size();
+        net->kc_skip.assign(n_ops, 0);
+        net->kc_src.assign(n_ops, -1);
+        net->kc_w_off.assign(n_ops, -1);
+        net->kc_bias_off.assign(n_ops, -1);
+        if (getenv("FRP_NO_KCONCAT")) continue;
+        for (size_t j = 0; j < n_ops; ++j) {
+            const frp_conv_op& c = net->ops[j];
+            // consumer: 3x3 conv over whole channel blocks with a plain residual, fp16 operands, one bias class
+            if (c.ksize != 3 || c.res_buf < 0 || (c.cin & 63) || c.flags != 0) continue;
+            // producer of the residual: the last writer of res_buf before j
+            int i = -1;
+            for (int q = (int)j - 1; q >= 0; --q)
+                if (net->ops[q].out_buf == c.res_buf || net->ops[q].out2_buf == c.res_buf) { i = q; break; }
+            if (i < 0) continue;
+            const frp_conv_op& d = net->ops[i];
+            if (d.out_buf != c.res_buf || d.ksize != 1 || d.stride != c.stride || d.act != FRP_ACT_NONE || d.res_buf >= 0 || d.flags != 0 ||
+                d.out2_buf >= 0 || d.cout != c.cout || (d.cin & 63) || !(c.cin == d.cin || c.cin == 2 * d.cin) || net->kc_skip[i])
+                continue;
+            // the shortcut map has no other reader while it holds this tensor; its input and the consumer's input stay
+            // untouched from the shortcut op to the consumer, and the consumer does not write over the shortcut's input
+            bool ok = c.out_buf != d.in_buf && c.in_buf != d.in_buf;
+            for (size_t q = (size_t)i + 1; q < n_ops && ok; ++q) {
+                const frp_conv_op& o = net->ops[q];
+                if (q != j && (o.in_buf == c.res_buf || o.res_buf == c.res_buf)) ok = false;     // another reader
+                if (q < j && (o.out_buf == d.in_buf || o.out2_buf == d.in_buf)) ok = false;       // shortcut input rewritten early
+                if (o.out_buf == c.res_buf || o.out2_buf == c.res_buf) break;                     // the buffer moves on to another tensor
+            }
+            if (!ok) continue;
+            if (net == &h->det) { for (int l = 0; l < 3; ++l) ok &= (int)hd.det_head_buf[l] != c.res_buf; }   // (read by the decode kernel)
+            else ok &= (int)hd.emb_out_buf != c.res_buf;
+            if (!ok) continue;
+            if (expanded.empty()) expanded.assign(data, data + hd.data_bytes);
+            const size_t k1 = (size_t)9 * c.cin, k2 = (size_t)d.cin, kt = k1 + k2;
+            const size_t wdst = (expanded.size() + 255) / 256 * 256;
+            expanded.resize(wdst + (size_t)c.cout * kt * 2);
+            const size_t bdst = (expanded.size() + 255) / 256 * 256;
+            expanded.resize(bdst + (size_t)c.cout * 4);
+            for (int r = 0; r < c.cout; ++r) {
+                memcpy(expanded.data() + wdst + ((size_t)r * kt) * 2, expanded.data() + c.w_off + (size_t)r * k1 * 2, k1 * 2);
+                memcpy(expanded.data() + wdst + ((size_t)r * kt + k1) * 2, expanded.data() + d.w_off + (size_t)r * k2 * 2, k2 * 2);
+                float b1, b2;
+                memcpy(&b1, expanded.data() + c.bias_off + (size_t)r * 4, 4);
+                memcpy(&b2, expanded.data() + d.bias_off + (size_t)r * 4, 4);
+                const float bs = b1 + b2;
+                memcpy(expanded.data() + bdst + (size_t)r * 4, &bs, 4);
+            }
+            net->kc_skip[i] = 1;
+            net->kc_src[j] = i;
+            net->kc_w_off[j] = (int64_t)wdst;
+            net->kc_bias_off[j] = (int64_t)bdst;
+            data = expanded.data();
+            data_bytes = expanded.size();
+        }
     }
     FRPCHK(ensure(h, h->wdata, data_bytes));
     HIPCHK(h, hipMemcpyAsync(h->wdata.p, data, data_bytes, hipMemcpyHostToDevice, h->stream));

@@ -27,6 +27,10 @@ struct ConvParams {
     const _Float16* res;    // [N,Ho,Wo,Cout] (or [N,Hr,Wr,Cout] with FRP_FLAG_RES_UP2) or null
     void* out;              // [N,Ho,Wo,Cout] fp16 (fp32 with FRP_FLAG_OUT_F32, fp8 with FRP_FLAG_OUT_FP8)
     void* out2;             // optional fp8 copy of an fp16 output (value / out_scale), or null
+    const _Float16* x2;     // K-concat (generic kernel, 3x3, Cin % 64 == 0): a second K segment = the 1x1 conv of tensor x2 [N,H,W,Cin2]
+                            // at the CENTRE tap's position (the block's stride-2 shortcut folded into its second conv);
+                            // w rows are then [3][3][Cin] followed by [Cin2], bias the sum of both.  null = none
+    int Cin2;               // channels of x2 (Cin2 % 64 == 0, Cin == Cin2 or 2 * Cin2)
     const float* wscale;    // FRP_FLAG_F8: per-cout scale of the fp8 weights
     float in_scale;         // FRP_FLAG_F8: the fp8 input tensor holds value / in_scale
     float out_scale;        // fp8 outputs hold value / out_scale
@@ -46,7 +50,8 @@ struct ConvParams {
                             // of the CUs idle (conv_common.h: conv_small_m), 1 = always, -1 = never (tests, A/B runs)
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
-    unsigned x_bytes, w_bytes;   // buffer-descriptor sizes (each < 2 GiB)
+    unsigned x_bytes, w_bytes, x2_bytes;   // buffer-descriptor sizes (each < 2 GiB)
+    int x2_shift;           // log2(Cin / Cin2)
 };
 
 hipError_t launch_conv(const ConvParams& p, hipStream_t stream);

@@ -163,10 +163,17 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
     """Greedy liveness-based mapping logical tensor -> physical buffer id.
     `pinned` tensors (network inputs/outputs) get private buffers."""
     last_use: Dict[str, int] = {}
+    producer = {l.dst: l for l in layers}
     for i, l in enumerate(layers):
         last_use[l.src] = i
         if l.res:
             last_use[l.res] = i
+            # K-concat (csrc/frp_api.cpp: frp_load_weights): the runtime folds a block's 1x1 strided shortcut conv into the
+            # 3x3 conv that adds it, which then reads the shortcut's INPUT - that tensor stays alive (and out of this
+            # conv's output buffer) until here
+            sc = producer.get(l.res)
+            if sc is not None and sc.k == 1 and l.k == 3 and sc.stride == l.stride and not (l.flags & ns.FLAG_RES_UP2):
+                last_use[sc.src] = max(last_use.get(sc.src, i), i)
         if getattr(l, "dst2", None):
             last_use.setdefault(l.dst2, i)          # a copy nobody reads still needs a buffer while it is written
     phys: Dict[str, int] = {}

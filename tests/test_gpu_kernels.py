@@ -686,6 +686,38 @@ def test_embedder_winograd_layers_vs_direct_and_oracle(engine, monkeypatch):
           "winograd vs direct", 1 - (wino * direct).sum(1).min())
 
 
+def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
+    """K-concat (conv_mfma.hip): the 1x1 stride-2 shortcut conv of every strided IResNet block rides in the k-loop of the
+    block's 3x3 stride-2 conv (its input at the centre tap as a second K segment, weights concatenated and biases summed at
+    load time) - four launches fewer, the same algorithmic FLOPs on the counters, the shortcut sum kept in fp32 instead of
+    being rounded to fp16 on its way through HBM: equal to the separate launches (FRP_NO_KCONCAT=1) to 1 - cos <= 1e-5 and
+    as close to the fp32 oracle; small batch (quarter tiles, direct family) and big batch (Cin = 2 Cin2 and Cin = Cin2)."""
+    rng = np.random.default_rng(21)
+    chips = rng.integers(0, 256, size=(70, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (2, 2, 2, 2))
+    ref = onet.emb_forward(raw, onet.emb_blob(chips[:4]))
+    out = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("FRP_NO_KCONCAT", "1")
+        engine.load_weights(blob)
+        for n in (4, 70):
+            engine.reset_counters()
+            e = engine.embed_aligned(chips[:n])
+            c = engine.counters()
+            out[mode, n] = (e, c["emb_conv_launches"], c["emb_conv_flops"])
+    monkeypatch.delenv("FRP_NO_KCONCAT")
+    engine.load_weights(blob)
+    for n in (4, 70):
+        (a, la, fa), (b, lb, fb) = out["fused", n], out["separate", n]
+        assert la == lb - 4 and abs(fa - fb) <= 1e-6 * fb
+        assert not np.array_equal(a, b)
+        assert 1 - (a * b).sum(1).min() <= 1e-5
+    for mode in ("fused", "separate"):
+        assert (out[mode, 4][0] * ref).sum(1).min() > 1 - 1e-3
+    assert 1 - (out["fused", 70][0][:4] * out["fused", 4][0]).sum(1).min() <= 2e-5     # (the two batches differ in kernel family)
+
+
 def test_gallery_reserve_commit_zero_copy_import(engine):
     """frp_gallery_reserve / _commit / _device_ptr (the RCCL all-gather lands in the snapshot the engine reserved,
     dist.allgather_gallery_into_engine): rows written into the reserved buffer by another producer on the GPU (torch here)
