@@ -44,6 +44,23 @@ def main():
     fused2 = "stem12_u8" in seq[0]["Kernel_Name"]
     det = walk(ns.detector_layers(), 1088, 1920, "det.in", frames)
     emb = walk(ns.iresnet_layers(), 112, 112, "emb.in", faces)
+    if not os.environ.get("FRP_NO_KCONCAT"):
+        # K-concat (csrc/frp_api.cpp: frp_load_weights): a strided block's 1x1 shortcut conv is not a launch of its own - it
+        # rides in the k-loop of the block's 3x3 stride-2 conv, which then reads the block input at every second pixel
+        # instead of the shortcut map: FLOPs and bytes of the pair are charged to that launch
+        fused, pend = [], None
+        for (l, h, w, fl, by) in emb:
+            if l.k == 1 and l.stride == 2 and l.name.endswith("downsample.0"):
+                pend = (l, h, w, fl, by)
+                continue
+            if pend is not None and l.res == pend[0].dst:
+                sl, sh, sw, sfl, sby = pend
+                oh, ow = ns.out_hw(sh, sw, 1, 2)
+                by = by - faces * oh * ow * l.cout * 2 + faces * oh * ow * sl.cin * 2 + sl.cout * sl.cin * 2     # no shortcut map; x at the centre taps
+                fl += sfl
+                pend = None
+            fused.append((l, h, w, fl, by))
+        emb = fused
     emb_stem = any("emb_stem" in r["Kernel_Name"] for r in seq)      # the embedder's first conv runs in its own kernel
     convs = iter(det[2 if fused2 else 1:] + emb[1 if emb_stem else 0:])
     prev_end, t0, tot, tot_gap = None, int(seq[0]["Start_Timestamp"]), 0.0, 0.0
