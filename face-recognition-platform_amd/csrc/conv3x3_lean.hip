@@ -80,17 +80,21 @@ __global__ __launch_bounds__(512, TP == 128 ? 4 : 2) void conv3x3_lean_kernel(Co
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     const int n_tiles = p.n_ptiles * p.n_ctiles;
+    const int G = (TP == 128 && p.n_workers) ? p.n_workers : (int)gridDim.x;      // workgroups that walk tiles
+    if constexpr (TP == 128) {
+        if ((int)blockIdx.x >= G) { conv_prefetch_weights(p, (int)blockIdx.x - G, (int)gridDim.x - G, 512); return; }
+    }
     // XCD-interleaved tile walk (see conv3x3_rows.hip)
     int t0, t1, tstep;
-    if ((gridDim.x & 7) == 0) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    if ((G & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = G >> 3;
         const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
         t0 = cs + j;
         t1 = ce;
         tstep = per;
     } else {
-        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
-        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        t0 = (int)((long)blockIdx.x * n_tiles / G);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / G);
         tstep = 1;
     }
     if (t0 >= t1) return;
@@ -464,7 +468,15 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
     const long slots = (long)ncu * (TP == 128 && !getenv("FRP_Q_ONE") ? 2 : 1);                // persistent: one workgroup per CU (quarter tiles: two)
-    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    p.n_workers = 0;
+    // a launch of at most 128 tiles (a call of up to ~20 faces: where the latency of ONE call is what counts) leaves three quarters
+    // of the slots empty: 64 more workgroups warm the L2s for the next launch.  Larger quarter-tile launches (config 4's ~36 faces
+    // on two lanes) keep their spare CUs for the other lane's kernels: there the prefetchers cost 4 % of the throughput.
+    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && !getenv("FRP_NO_PREFETCH")) {
+        p.n_workers = (int)grid;
+        grid += CONV_PF_WGS;
+    }
     if (grid > 256) p.stamps = nullptr;                                // (the diagnostic stamp buffer holds 256 workgroups)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     return hipGetLastError();

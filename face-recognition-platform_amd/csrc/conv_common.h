@@ -66,6 +66,25 @@ static inline bool conv_small_m(const ConvParams& p, long default_tiles, int ncu
     return ncu > 0 && default_tiles * 2 <= ncu;
 }
 
+// Weight prefetch of a quarter-tile launch (ConvParams::pf_ptr): workgroup k of the n_pf extra ones (k = blockIdx - workers; round-robin
+// dispatch puts workgroup b on XCD b % 8) pulls its share of the next launch's weights through the L2 of ITS XCD - every XCD reads the
+// whole region, in n_pf / 8 slices.  Read-only, results unused: nothing to synchronise with.
+#define CONV_PF_WGS 64
+__device__ __forceinline__ void conv_prefetch_weights(const ConvParams& p, int k, int n_pf, int nthreads) {
+    const int per_xcd = n_pf >> 3;
+    if (per_xcd <= 0 || !p.pf_ptr) return;
+    const int q = k >> 3;                                            // slice index within this XCD's workgroups
+    const unsigned n16 = p.pf_bytes >> 4;
+    const unsigned lo = (unsigned)((unsigned long long)n16 * q / per_xcd), hi = (unsigned)((unsigned long long)n16 * (q + 1) / per_xcd);
+    const uint4* src = reinterpret_cast<const uint4*>(p.pf_ptr);
+    unsigned acc = 0;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += nthreads) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u && p.stamps) p.stamps[0] = acc;          // (keeps the loads; never true in practice, harmless if it is)
+}
+
 // q = m / d, r = m % d for 0 <= m < 2^24 via a float reciprocal and one correction step
 // (an integer division costs ~40 instructions; the prologue needs two per pixel row)
 __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {

@@ -75,16 +75,20 @@ __global__ __launch_bounds__(NW * 64, TP == 128 ? 4 : 2) void conv_mfma_kernel(C
     // XCD-interleaved walk (see conv3x3_rows.hip): the workgroups of one L2 (b, b+8, ...) share a contiguous
     // chunk of the tile list and walk it interleaved, so neighbouring tiles - same input rows, both cout tiles of
     // a pixel tile, the k-slices of one split-K tile - are in flight on the same L2 at the same time.
+    const int G = (TP == 128 && p.n_workers) ? p.n_workers : (int)gridDim.x;      // workgroups that walk tiles (the others: conv_prefetch_weights)
+    if constexpr (TP == 128) {
+        if ((int)blockIdx.x >= G) { conv_prefetch_weights(p, (int)blockIdx.x - G, (int)gridDim.x - G, NW * 64); return; }
+    }
     int t0, t1, tstep;
-    if ((gridDim.x & 7) == 0) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    if ((G & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = G >> 3;
         const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
         t0 = cs + j;
         t1 = ce;
         tstep = per;
     } else {
-        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
-        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        t0 = (int)((long)blockIdx.x * n_tiles / G);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / G);
         tstep = 1;
     }
     if (t0 >= t1) return;
@@ -449,7 +453,15 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     // persistent: as many workgroups per CU as the LDS ring allows (1 or 2), each walks a
     // contiguous range of tiles
     const long slots = (long)ncu * (lds <= 80 * 1024 ? 2 : 1);
-    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    p.n_workers = 0;
+    // a launch of at most 128 tiles (a call of up to ~20 faces: where the latency of ONE call is what counts) leaves three quarters
+    // of the slots empty: 64 more workgroups warm the L2s for the next launch.  Larger quarter-tile launches (config 4's ~36 faces
+    // on two lanes) keep their spare CUs for the other lane's kernels: there the prefetchers cost 4 % of the throughput.
+    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && !getenv("FRP_NO_PREFETCH")) {
+        p.n_workers = (int)grid;
+        grid += CONV_PF_WGS;
+    }
     if (grid > 256) p.stamps = nullptr;                                // (the diagnostic stamp buffer holds 256 workgroups)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();

@@ -448,6 +448,23 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
                 }
             }
         }
+        // the weights the NEXT launch will stream (a quarter-tile launch with CUs to spare warms the L2s with them: conv_common.h)
+        for (size_t nx = opi + 1; nx < net.ops.size(); ++nx) {
+            if (nx < net.kc_skip.size() && net.kc_skip[nx]) continue;
+            const frp_conv_op& no = net.ops[nx];
+            const size_t es = (no.flags & FRP_OPFLAG_FP8_MFMA) ? 1 : 2;
+            if (nx < net.kc_src.size() && net.kc_src[nx] >= 0) {
+                p.pf_ptr = wbase + net.kc_w_off[nx];
+                p.pf_bytes = (unsigned)((size_t)no.cout * (9 * (size_t)no.cin + net.ops[net.kc_src[nx]].cin) * 2);
+            } else if (allow_wino && nx < net.wino_off.size() && net.wino_off[nx] >= 0) {
+                p.pf_ptr = wbase + net.wino_off[nx];
+                p.pf_bytes = (unsigned)std::min<size_t>(conv3x3_wino_image_bytes(no.cin, no.cout), 0x7fffffffu);
+            } else {
+                p.pf_ptr = wbase + no.w_off;
+                p.pf_bytes = (unsigned)std::min<size_t>((size_t)no.cout * no.ksize * no.ksize * no.cin * es, 0x7fffffffu);
+            }
+            break;
+        }
         hipError_t e = launch_conv(p, h->stream);
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_conv: ") + hipGetErrorString(e));
         const int pad = op.ksize / 2;

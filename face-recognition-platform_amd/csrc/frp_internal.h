@@ -46,6 +46,9 @@ struct ConvParams {
     int n_cu;               // compute units (input of the device-side split-K choice)
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
     int dbg;                // A/B switch (tests, conv_bench): 1 = generic kernel also for row-patch shapes
+    const void* pf_ptr;     // quarter-tile launches with CUs to spare: the NEXT launch's weights (pf_bytes of them), read once by 64 extra
+    unsigned pf_bytes;      // workgroups - 8 per XCD - while this launch runs, so that the next one streams them from L2 (a call of a few
+    int n_workers;          // faces reads every weight once, cold: its k-steps wait for HBM); n_workers: set by the launcher (0 = the whole grid works)
     int small_m;            // quarter tiles (128 pixels x 64 couts, two workgroups per CU): 0 = when the default tiling leaves half
                             // of the CUs idle (conv_common.h: conv_small_m), 1 = always, -1 = never (tests, A/B runs)
     // derived by launch_conv():

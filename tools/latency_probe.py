@@ -10,9 +10,9 @@ for B in (1, 2, 4, 8, 32):
     fr = np.random.default_rng(B).integers(0,256,(B,1080,1920,3),dtype=np.uint8)
     eng.upload_frames(fr)
     for K in (1, 10):
-        for _ in range(3): eng.process_resident(K, flags=1); eng.fetch_results()
+        for _ in range(30): eng.process_resident(K, flags=1); eng.fetch_results()     # (clocks ramp up over the first calls of a small load)
         t=time.perf_counter()
-        n=20
+        n=40
         for _ in range(n): eng.process_resident(K, flags=1); eng.fetch_results()
         dt=(time.perf_counter()-t)/n
         print(f"B={B:2d} K={K:2d}: {dt*1e3:7.3f} ms per call ({B/dt:7.1f} frames/s)")
