@@ -467,13 +467,13 @@ static hipError_t launch_lean_cfg(const ConvParams& p0, hipStream_t stream) {
     if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
-    const long slots = (long)ncu * (TP == 128 && !getenv("FRP_Q_ONE") ? 2 : 1);                // persistent: one workgroup per CU (quarter tiles: two)
+    const long slots = (long)ncu * (TP == 128 ? 2 : 1);                // persistent: one workgroup per CU (quarter tiles: two)
     unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     p.n_workers = 0;
     // a launch of at most 128 tiles (a call of up to ~20 faces: where the latency of ONE call is what counts) leaves three quarters
     // of the slots empty: 64 more workgroups warm the L2s for the next launch.  Larger quarter-tile launches (config 4's ~36 faces
     // on two lanes) keep their spare CUs for the other lane's kernels: there the prefetchers cost 4 % of the throughput.
-    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && !getenv("FRP_NO_PREFETCH")) {
+    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && conv_prefetch_enabled()) {
         p.n_workers = (int)grid;
         grid += CONV_PF_WGS;
     }
@@ -498,10 +498,14 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream) {
         return launch_lean_cfg<128, 4, 2, true, 256>(p, stream);
     }
     {                                              // few tiles (small maps, few faces): quarter tiles, two workgroups per CU
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        int ncu = p.n_cu;                          // (set by the engine; standalone callers: ask the runtime)
+        if (ncu <= 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+            ncu = device_cu_count(dev);
+        }
         const long def_tiles = p.Cout > 64 ? (long)((p.M + 255) / 256) * ((p.Cout + 127) / 128) : (long)((p.M + 511) / 512);
-        if (conv_small_m(p, def_tiles, device_cu_count(dev))) return launch_lean_cfg<64, 4, 2, false, 128>(p, stream);
+        if (conv_small_m(p, def_tiles, ncu)) return launch_lean_cfg<64, 4, 2, false, 128>(p, stream);
     }
     if (p.Cout > 64) return launch_lean_cfg<128, 4, 2, false, 256>(p, stream);
     if (p.dbg & 128) return launch_lean_cfg<64, 8, 1, false, 256>(p, stream);      // A/B: the 256-pixel tile (1.5 reads per MFMA)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "frp_internal.h"
 
 namespace frp {
@@ -70,6 +71,10 @@ static inline bool conv_small_m(const ConvParams& p, long default_tiles, int ncu
 // dispatch puts workgroup b on XCD b % 8) pulls its share of the next launch's weights through the L2 of ITS XCD - every XCD reads the
 // whole region, in n_pf / 8 slices.  Read-only, results unused: nothing to synchronise with.
 #define CONV_PF_WGS 64
+static inline bool conv_prefetch_enabled() {                         // FRP_NO_PREFETCH=1 (read once): A/B runs
+    static const bool on = getenv("FRP_NO_PREFETCH") == nullptr;
+    return on;
+}
 __device__ __forceinline__ void conv_prefetch_weights(const ConvParams& p, int k, int n_pf, int nthreads) {
     const int per_xcd = n_pf >> 3;
     if (per_xcd <= 0 || !p.pf_ptr) return;

@@ -458,7 +458,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     // a launch of at most 128 tiles (a call of up to ~20 faces: where the latency of ONE call is what counts) leaves three quarters
     // of the slots empty: 64 more workgroups warm the L2s for the next launch.  Larger quarter-tile launches (config 4's ~36 faces
     // on two lanes) keep their spare CUs for the other lane's kernels: there the prefetchers cost 4 % of the throughput.
-    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && !getenv("FRP_NO_PREFETCH")) {
+    if (TP == 128 && p.pf_ptr && p.pf_bytes >= 4096 && grid <= 128 && (long)grid + CONV_PF_WGS <= slots && conv_prefetch_enabled()) {
         p.n_workers = (int)grid;
         grid += CONV_PF_WGS;
     }
@@ -522,9 +522,12 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         if (!conv3x3_rows_eligible(p) || (p.Cin & 127) || !p.wscale || !(p.in_scale > 0.f)) return hipErrorInvalidValue;
         return launch_conv3x3_lean(p, stream);
     }
-    int dev_ = 0;
-    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
-    const int ncu_ = device_cu_count(dev_);
+    int ncu_ = p.n_cu;                               // (set by the engine; standalone callers: ask the runtime)
+    if (ncu_ <= 0) {
+        int dev_ = 0;
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+        ncu_ = device_cu_count(dev_);
+    }
     // few 256 x 128 tiles (small pyramid scales, a handful of faces): quarter tiles, two workgroups per CU (conv_small_m)
     const bool few = conv_small_m(p, (long)((p.M + 255) / 256) * ((p.Cout + 127) / 128), ncu_);
     // (a caller that hands over the Winograd image has chosen the kernel FAMILY - frp_api.cpp: run_embed, by the slots of the
