@@ -327,6 +327,30 @@ def test_blob_layout_and_buffer_liveness():
         assert op[10] % 16 == 0 and op[11] % 16 == 0 and 0 <= out_buf < n_det_bufs
 
 
+def test_buffer_plan_keeps_the_block_input_for_the_k_concat_consumer():
+    """K-concat (csrc/frp_api.cpp: frp_load_weights folds a strided block's 1x1 shortcut conv into the 3x3 conv that adds
+    it): the fused conv reads the shortcut's INPUT, so the packer must keep that tensor alive until then and must not hand
+    its buffer to the conv's output - the runtime refuses the fusion otherwise (and the four launches stay separate)."""
+    for blocks in ((1, 1, 1, 1), (3, 13, 30, 3)):
+        layers = netspec.iresnet_layers(blocks)
+        phys, n = weights.assign_buffers(layers, ["emb.in", "emb.out"])
+        prod = {l.dst: l for l in layers}
+        fused = 0
+        for j, l in enumerate(layers):
+            sc = prod.get(l.res) if l.res else None
+            if sc is None or sc.k != 1:
+                continue
+            fused += 1
+            assert l.k == 3 and l.stride == sc.stride == 2
+            assert phys[l.dst] != phys[sc.src] and phys[l.src] != phys[sc.src]
+            # nobody writes into the shortcut input's buffer between the shortcut op and its consumer
+            i = layers.index(sc)
+            for q in layers[i + 1: j]:
+                assert phys[q.dst] != phys[sc.src], q.name
+        assert fused == 4
+        assert n <= 9                                   # (liveness still recycles: a handful of buffers whatever the depth)
+
+
 def test_arcface_checkpoint_loader_roundtrip(tmp_path):
     """a checkpoint in the public arcface_torch naming loads into the raw dict pack_blob consumes"""
     raw = weights.make_synthetic_raw(11, (1, 1, 1, 1), (1, 2, 1, 1), want_det=False)
