@@ -79,7 +79,8 @@ __device__ __forceinline__ void conv_prefetch_weights(const ConvParams& p, int k
     const int per_xcd = n_pf >> 3;
     if (per_xcd <= 0 || !p.pf_ptr) return;
     const int q = k >> 3;                                            // slice index within this XCD's workgroups
-    const unsigned n16 = p.pf_bytes >> 4;
+    // at most 3 MiB (an XCD's L2 holds 4): the head of a larger tensor (stage 4's 4.7 MB; the FC's 25.7 MB would only evict itself)
+    const unsigned n16 = (p.pf_bytes < (3u << 20) ? p.pf_bytes : (3u << 20)) >> 4;
     const unsigned lo = (unsigned)((unsigned long long)n16 * q / per_xcd), hi = (unsigned)((unsigned long long)n16 * (q + 1) / per_xcd);
     const uint4* src = reinterpret_cast<const uint4*>(p.pf_ptr);
     unsigned acc = 0;
