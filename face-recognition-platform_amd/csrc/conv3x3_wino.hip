@@ -77,7 +77,10 @@ __device__ __forceinline__ void wino_load_res(const ConvParams& p, uint4 (&r)[PB
 }
 
 // (Requesting the first unit's residual under the tile's last MFMAs - 8 more live registers in the k-loop's last sub-step -
-// measured slower: 69.1 vs 66.2 us on the stage-3 shape.)
+// measured slower: 69.1 vs 66.2 us on the stage-3 shape.  Tried again in the second half of round 3 in two forms that should
+// not have cost registers - the request written into the raw-fragment registers, dead in a tile's last sub-step; the last
+// channel block peeled into its own copy of the body, `last_cb` a literal -: 25 / 26 spilled registers instead of 12, some of
+// them in the per-tile head, embedder 8.02 vs 7.83 ms in the same-box A/B.  The ~2 us stay exposed: 0.26 ms of a step.)
 template <int PB, bool FULL, int ACT, int RES>
 __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16 (&acc)[4][PB][2],
                                                    const float* lds_bias, const float* lds_slope, int m0, int c0, int pair0, int crow0,
