@@ -123,6 +123,29 @@ QUARTER_CASES = [c for c in CONV_CASES if c[3] % 64 == 0 and not (c[9] & 2)] + [
 ]
 
 
+def test_conv_quarter_tiles_race_screen(engine):
+    """Two workgroups per CU load the LDS enough to expose a write-after-read hole in the k-step protocol (a fragment read
+    issued before a barrier, still in flight when another wave - released by that barrier - restages the ring slot; the
+    compiler had sunk the MFMAs that retire such reads below the barrier): before `retire_lds_reads()` one launch in
+    four of this layer came back with one stale 8-row weight piece in one wave.  490 quarter tiles on 512
+    slots, 30 launches, every one bit-identical to the default tiles."""
+    rng = np.random.default_rng(2024)
+    N, H, W, C = 5, 112, 112, 64
+    x = rng.standard_normal((N, H, W, C)).astype(np.float16)
+    w = (rng.standard_normal((C, 3, 3, C)) / np.sqrt(9 * C)).astype(np.float16)
+    bias = rng.standard_normal((9, C)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, C).astype(np.float32)
+    ref = engine.conv2d(x, w, bias, act=2, slope=slope, flags=1 | TILES_DEFAULT)
+    for _ in range(30):
+        got = engine.conv2d(x, w, bias, act=2, slope=slope, flags=1 | TILES_QUARTER)
+        assert np.array_equal(ref.view(np.uint16), got.view(np.uint16))
+    # ... and the generic kernel's quarter tiles (stride 2: 1,225 tiles, several per workgroup)
+    ref = engine.conv2d(x, w, bias[0], stride=2, act=0, flags=TILES_DEFAULT)
+    for _ in range(10):
+        got = engine.conv2d(x, w, bias[0], stride=2, act=0, flags=TILES_QUARTER)
+        assert np.array_equal(ref.view(np.uint16), got.view(np.uint16))
+
+
 @pytest.mark.parametrize("case", QUARTER_CASES)
 def test_conv_quarter_tiles_equal_default_tiles(engine, case):
     """Quarter tiles (small maps / few faces) keep the k order of the default tiles -> identical bits, in the row-patch
