@@ -73,6 +73,38 @@ def test_process_frames_end_to_end(engine):
     assert total >= 4
 
 
+def test_full_size_end_to_end_1080p_r100_vs_oracle(engine):
+    """The whole path at the headline size, not piecewise: ONE 1920 x 1080 frame through the full detector (1088 x 1920 canvas,
+    85,680 anchors), threshold + NMS, 5-point alignment, IResNet-100 and a 3,000-row gallery, against the fp32 oracle's
+    whole chain (`oracle/network.py: process_frames`) on the same frame and weights: same face count and order, boxes and
+    landmarks within 0.5 px, scores 2e-3, embeddings cos >= 1 - 1e-3, identical top-1, match cosine 2e-3.  (A call of
+    this size takes the direct kernels in quarter tiles for the embedder and the default tiles for the detector.)"""
+    rng = np.random.default_rng(4242)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (3, 13, 30, 3))
+    engine.load_weights(blob)
+    H, W, K = 1080, 1920, 10
+    fr = _frames(rng, 1, H, W)
+    thr, _ = _threshold_with_margin(raw, fr, (1088, 1920), lo_cnt=2, hi_cnt=40)
+    r = onet.process_frames(raw, fr, None, (1088, 1920), score_thresh=thr, nms_iou=0.4, max_faces=K)[0]
+    n = len(r["boxes"])
+    assert 2 <= n <= K
+    G = rng.standard_normal((3000, 512)).astype(np.float32)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    slots = rng.choice(3000, size=n, replace=False)
+    G[slots] = r["emb"]
+    engine.gallery_set(G)
+    out = engine.process_frames(fr, max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+    assert out["counts"][0] == n
+    assert np.abs(out["boxes"][0, :n] - r["boxes"]).max() < 0.5
+    assert np.abs(out["kps"][0, :n] - r["kps"]).max() < 0.5
+    assert np.abs(out["scores"][0, :n] - r["scores"]).max() < 2e-3
+    cos = (out["emb"][0, :n] * r["emb"]).sum(1)
+    assert cos.min() > 1 - 1e-3, cos
+    assert np.array_equal(out["match_idx"][0, :n], slots)
+    assert np.abs(out["match_cos"][0, :n] - 1.0).max() < 2e-3
+    print("full-size end to end:", n, "faces, 1 - cos max", float(1 - cos.min()), "box err", float(np.abs(out["boxes"][0, :n] - r["boxes"]).max()))
+
+
 def test_threshold_mode_face_count_stays_on_the_device(engine, monkeypatch):
     """Threshold mode (routes/camera.py:232-259: the reference's loop) without the mid-pipeline host round trip: align,
     embedder, l2norm and matcher read the face count from device memory.  Bit for bit the results of the former path
