@@ -159,6 +159,9 @@ def fold_layer(raw: Dict[str, np.ndarray], l: ns.ConvLayer, return_w64: bool = F
     return w16, bias.astype(np.float32), slope
 
 
+KCONCAT_LIVENESS = True     # tests flip it to pack a blob with the buffer plan of older packers (the runtime must then leave the blocks unfused)
+
+
 def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[str, int], int]:
     """Greedy liveness-based mapping logical tensor -> physical buffer id.
     `pinned` tensors (network inputs/outputs) get private buffers."""
@@ -172,7 +175,7 @@ def assign_buffers(layers: List[ns.ConvLayer], pinned: List[str]) -> Tuple[Dict[
             # 3x3 conv that adds it, which then reads the shortcut's INPUT - that tensor stays alive (and out of this
             # conv's output buffer) until here
             sc = producer.get(l.res)
-            if sc is not None and sc.k == 1 and l.k == 3 and sc.stride == l.stride and not (l.flags & ns.FLAG_RES_UP2):
+            if KCONCAT_LIVENESS and sc is not None and sc.k == 1 and l.k == 3 and sc.stride == l.stride and not (l.flags & ns.FLAG_RES_UP2):
                 last_use[sc.src] = max(last_use.get(sc.src, i), i)
         if getattr(l, "dst2", None):
             last_use.setdefault(l.dst2, i)          # a copy nobody reads still needs a buffer while it is written

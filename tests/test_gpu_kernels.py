@@ -738,6 +738,17 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
         assert 1 - (a * b).sum(1).min() <= 1e-5
     for mode in ("fused", "separate"):
         assert (out[mode, 4][0] * ref).sum(1).min() > 1 - 1e-3
+    # a blob with the buffer plan of older packers (a strided block's output may reuse the block input's buffer): the
+    # runtime's precondition check leaves those blocks unfused - the separate launches' bits, none fewer
+    from frp_amd import weights
+    monkeypatch.setattr(weights, "KCONCAT_LIVENESS", False)
+    old_blob = weights.pack_blob(raw, (1, 1, 1, 1), (2, 2, 2, 2))
+    monkeypatch.setattr(weights, "KCONCAT_LIVENESS", True)
+    engine.load_weights(old_blob)
+    engine.reset_counters()
+    e = engine.embed_aligned(chips[:4])
+    assert np.array_equal(e, out["separate", 4][0]) and engine.counters()["emb_conv_launches"] == out["separate", 4][1]
+    engine.load_weights(blob)
     assert 1 - (out["fused", 70][0][:4] * out["fused", 4][0]).sum(1).min() <= 2e-5     # (the two batches differ in kernel family)
 
 
