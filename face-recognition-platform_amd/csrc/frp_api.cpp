@@ -632,13 +632,14 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
 }
 
 // chips for n faces are in emb.bufs[in]; run embedder + l2norm (+ fp16 copy for the matcher)
-// Kernel family of an embedder pass.  The Winograd kernel (256 x 128 tiles only) pays from about a hundred faces up; below,
-// the direct kernels in quarter tiles are up to 2.6 x faster (tools/small_m_probe.py).  The two families differ in the last
+// Kernel family of an embedder pass.  The Winograd kernel (256 x 128 tiles only) pays from about 128 faces up (end to end,
+// tools/family_crossover.py: 80 slots 5.06 vs 4.62 ms, 100 / 128 slots equal, 160 slots 7.58 vs 7.78); below, the direct kernels in
+// quarter tiles are up to 2.6 x faster per layer (tools/small_m_probe.py).  The two families differ in the last
 // bits (1 - cos 1.6e-6), so the choice is made ONCE per call, from a count that does not depend on what the detector
 // found: `family_count` = the slots of the call (B x K of a process call, whether the face count stays on the device or
 // not; the faces handed to the embed / finish calls).  Within a family every tile size gives the same bits, so a face's
 // embedding depends on the call's slot count being above or below FRP_WINO_MIN_FACES and on nothing else in the batch.
-#define FRP_WINO_MIN_FACES 65
+#define FRP_WINO_MIN_FACES 128
 int run_embed(frp_handle* h, int n, const int32_t* n_dev = nullptr, int family_count = -1) {
     if (n <= 0) return FRP_OK;
     if (family_count < 0) family_count = n;

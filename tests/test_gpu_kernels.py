@@ -553,7 +553,7 @@ def test_match_topk_rejects_bad_k(engine):
 def test_embedder_large_batch_equals_small_batch_and_oracle(engine, monkeypatch):
     """IResNet-100 on 330 faces (every stage spans several tiles per workgroup: XCD-interleaved walk, ragged last
     tiles) gives, face by face, the result of a 3-face call on the same tile class up to the fp32 summation order of the
-    FC (its split-K factor depends on the batch), which the fp32 oracle confirms.  Left to itself a call of fewer than 65
+    FC (its split-K factor depends on the batch), which the fp32 oracle confirms.  Left to itself a call of fewer than 128
     faces takes the DIRECT kernels also where the big batch runs the Winograd kernel (28 x 28, 14 x 14): the two
     families agree to 1 - cos <= 2e-5 (measured 1.6e-6), three orders of magnitude inside the 1e-3 bar."""
     rng = np.random.default_rng(404)
@@ -567,7 +567,7 @@ def test_embedder_large_batch_equals_small_batch_and_oracle(engine, monkeypatch)
     monkeypatch.delenv("FRP_WINO_MIN_FACES")
     assert np.abs(big[pick] - small).max() < 1e-6
     few = engine.embed_aligned(chips[pick])                       # the default for three faces: direct kernels, quarter tiles
-    sixty = engine.embed_aligned(chips[:64])                      # ... as for any call below FRP_WINO_MIN_FACES = 65 slots,
+    sixty = engine.embed_aligned(chips[:64])                      # ... as for any call below FRP_WINO_MIN_FACES = 128 slots,
     assert np.abs(sixty[pick[0]] - few[0]).max() < 1e-6           # whatever tile sizes its layers take
     assert not np.array_equal(few, small)
     assert 1 - (few * small).sum(1).min() <= 2e-5
@@ -714,7 +714,7 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
     block's 3x3 stride-2 conv (its input at the centre tap as a second K segment, weights concatenated and biases summed at
     load time) - four launches fewer, the same algorithmic FLOPs on the counters, the shortcut sum kept in fp32 instead of
     being rounded to fp16 on its way through HBM: equal to the separate launches (FRP_NO_KCONCAT=1) to 1 - cos <= 1e-5 and
-    as close to the fp32 oracle; small batch (quarter tiles, direct family) and big batch (Cin = 2 Cin2 and Cin = Cin2)."""
+    as close to the fp32 oracle; 4 faces (quarter tiles) and 70 faces (default tiles where a launch has enough of them); Cin = 2 Cin2 and Cin = Cin2."""
     rng = np.random.default_rng(21)
     chips = rng.integers(0, 256, size=(70, 112, 112, 3), dtype=np.uint8)
     raw, blob = get_raw_and_blob((1, 1, 1, 1), (2, 2, 2, 2))
@@ -749,7 +749,7 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
     e = engine.embed_aligned(chips[:4])
     assert np.array_equal(e, out["separate", 4][0]) and engine.counters()["emb_conv_launches"] == out["separate", 4][1]
     engine.load_weights(blob)
-    assert 1 - (out["fused", 70][0][:4] * out["fused", 4][0]).sum(1).min() <= 2e-5     # (the two batches differ in kernel family)
+    assert np.abs(out["fused", 70][0][:4] - out["fused", 4][0]).max() < 1e-6     # (same family, other tile sizes; the FC's split-K factor differs)
 
 
 def test_gallery_reserve_commit_zero_copy_import(engine):
