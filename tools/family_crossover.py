@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Where the embedder's two kernel families cross END TO END: a process call (resident 1080p frames, forced K, IResNet-100, 100 k
+gallery, results fetched) of 60 ... 160 face slots on the Winograd family (FRP_WINO_MIN_FACES=1) and on the direct family
+(=100000), same process, alternating.  The per-layer probe (tools/small_m_probe.py) put the crossover near 65 faces; the whole call
+puts it at ~128 - the value of FRP_WINO_MIN_FACES in csrc/frp_api.cpp.      python tools/family_crossover.py"""
 import sys, time, os, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import frp_amd_loader
 from frp_amd import native, weights
 blob = weights.pack_blob(weights.make_synthetic_raw(7))

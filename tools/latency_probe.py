@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import frp_amd_loader
 from frp_amd import native, weights
 blob = weights.pack_blob(weights.make_synthetic_raw(7))
