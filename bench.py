@@ -12,7 +12,40 @@ import os
 import sys
 import time
 
-import numpy as np
+
+
+def _self_launch_if_needed(argv):
+    """`python bench.py --gpus N` typed without a launcher (WORLD_SIZE unset, N > 1): start the N ranks as FRESH child
+    processes - `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, rendezvous on 127.0.0.1 -
+    before this process has imported anything that could touch the GPU (a process that has initialised HIP must not
+    exec or fork GPU children), hand rank 0's JSON line through on stdout and exit with the children's code.  The
+    reference's fan-out this replaces: one task per camera on a ThreadPoolExecutor(4),
+    backend/app/routes/camera.py:30,277-279,304-305.  Under a launcher (WORLD_SIZE set) and for N = 1 this is a no-op."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["FRP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed(sys.argv[1:])
+
+import numpy as np  # noqa: E402
 
 # two lanes per GPU next to torch + RCCL need more than the default 4 hardware queues (see native.py); before any HIP call
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -228,6 +261,41 @@ def run_config4(args, json_fd):
         e_.close()
 
 
+def run_rehearsal_cpu(args, json_fd, rank, world):
+    """--rehearse-cpu: the multi-rank plumbing of the headline command without a GPU (gloo): process group from the
+    launcher's environment, stream -> rank split, this rank's gallery shard, the one collective (all-gather of the shards
+    into the full matrix), the cross-rank consistency check and rank 0's JSON line.  Nothing is measured: `value` is null."""
+    import torch
+    import torch.distributed as dist
+    from frp_amd import dist as fdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = args.gallery
+    first, cnt = fdist.shard_range(N, rank, world)
+    shard = fdist.normalize_rows_f16(gallery_rows(N, first, cnt)) if cnt else np.zeros((0, 512), np.float16)
+    full = fdist.allgather_gallery(shard, N)
+    gallery_sum = fdist.gallery_checksum(full)
+    sums = [None] * world
+    dist.all_gather_object(sums, gallery_sum)
+    assert all(s_ == sums[0] for s_ in sums), f"gathered galleries differ across ranks: {sums}"
+    t = torch.tensor([1.0 + rank])
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        line = {"metric": "faces/sec (detect+embed+match) on 1080p @ 100k gallery", "value": None, "unit": "faces/s",
+                "n_gpus": 0, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": "CPU rehearsal of the multi-rank plumbing (gloo, no GPU, nothing measured)",
+                           "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "gallery": N,
+                           "streams": world, "streams_of_rank": [fdist.streams_of_rank(world, r, world) for r in range(world)],
+                           "ranks_seen": [int(x.item()) - 1 for x in every], "gathered_gallery_checksum": gallery_sum,
+                           "launcher": ("bench.py started its own ranks (torch.distributed.run, 127.0.0.1)"
+                                        if os.environ.get("FRP_BENCH_SELF_LAUNCHED") == "1" else "external torch.distributed.run")}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"],
@@ -251,6 +319,9 @@ def main():
                     help="steps of the host-to-host side measurement (-1 = as many as --steps, 0 = skip)")
     ap.add_argument("--threshold-steps", type=int, default=-1,
                     help="steps of the threshold-mode (NMS on, ragged face counts) side measurement (-1 = --steps, 0 = skip)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU: run only the multi-rank plumbing of this command (launcher, rendezvous, stream -> rank split, gallery "
+                         "shard all-gather, JSON line) on the gloo backend; `value` is null.  What tests/test_bench_launcher.py drives")
     args = ap.parse_args()
 
     # Everything except the final JSON line goes to stderr: RCCL prints a version banner on the
@@ -271,6 +342,9 @@ def main():
         if args.gpus != 1 or world != 1:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
             sys.exit(2)
+    if args.rehearse_cpu:
+        run_rehearsal_cpu(args, json_fd, rank, world)
+        return
     dist = None
     # FRP_FORCE_DIST=1 exercises the RCCL path (process group, gallery all-gather, device hand-off)
     # even with one rank -- used to rehearse the multi-GPU code on a one-GPU box
@@ -298,6 +372,13 @@ def main():
         import torch
         from frp_amd import dist as fdist
         fdist.allgather_gallery_into_engine(lanes, N, lambda first, cnt: gallery_rows(N, first, cnt), local_rank)
+        # every rank must now hold the same matrix: checksum of the committed snapshot (device memory), compared across ranks
+        g_view = torch.as_tensor(fdist._DevicePtr(eng.gallery_device_ptr(), N, 512), device=torch.device("cuda", local_rank))
+        gallery_sum = fdist.gallery_checksum(g_view)
+        sums = [None] * dist.get_world_size()
+        dist.all_gather_object(sums, gallery_sum)
+        assert all(s_ == sums[0] for s_ in sums), f"gathered galleries differ across ranks: {sums}"
+        rccl_ranks = dist.get_world_size()
     else:
         g_ = gallery_rows(N, 0, N)
         for e_ in lanes:
@@ -405,9 +486,13 @@ def main():
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         import torch
         t = torch.tensor([dt], device="cuda")
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        per_rank = [round(args.steps * B * K / float(x.item()), 1) for x in every]     # each rank's own clock
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # The same with HOST frames every step (never `value`): each lane's thread uploads its batch from page-locked memory
@@ -641,6 +726,12 @@ def main():
                 "achieved": round(emb_tf, 2), "peak": MFMA_PEAK_FP8, "unit": "TFLOP/s", "frac": round(emb_tf / MFMA_PEAK_FP8, 4),
                 "fp8_share_of_embedder_flops": round(ctr["f8_conv_flops"] / max(1.0, ctr["emb_conv_flops"]), 4),
                 "fp8_launches_per_step": ctr["f8_conv_launches"] // max(1, args.steps)}
+        if dist is not None:       # (single-process runs keep the line byte-compatible: no extra keys)
+            out["config"]["rccl_ranks"] = rccl_ranks
+            out["config"]["faces_per_s_per_rank"] = per_rank
+            out["config"]["gathered_gallery_checksum"] = gallery_sum
+            out["config"]["launcher"] = ("bench.py started its own ranks (torch.distributed.run, 127.0.0.1)"
+                                         if os.environ.get("FRP_BENCH_SELF_LAUNCHED") == "1" else "external torch.distributed.run")
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(raw, frames, K, N, args.cpu_frames)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

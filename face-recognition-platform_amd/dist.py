@@ -69,6 +69,15 @@ def allgather_gallery(shard_f16, n_total: int, device=None, out=None):
     return out[:n_total]
 
 
+def gallery_checksum(mat) -> int:
+    """position-weighted checksum of a unit fp16 matrix (torch tensor, host or device): the sum of its bit patterns
+    weighted by position modulo 2^61 - equal on every rank iff the all-gather left the same bytes in the same rows"""
+    import torch
+    v = mat.contiguous().view(torch.int16).to(torch.int64).reshape(-1) & 0xFFFF
+    w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191) + 1
+    return int(((v * w).sum() % ((1 << 61) - 1)).item())
+
+
 def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int, int], np.ndarray], local_rank: int):
     """Rank r builds rows shard_range(n_total, r, R) on the host, uploads them as unit fp16 and all-gathers over RCCL
     STRAIGHT INTO the snapshot the first engine reserved (frp_gallery_reserve / frp_gallery_commit): the matrix exists
