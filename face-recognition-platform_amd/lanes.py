@@ -30,36 +30,56 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
     host thread each) turn items of `batches` into results; results are yielded in submission order; at most
     2 x len(workers) items are taken ahead of the consumer.  An exception of the iterator or of a worker is raised in
     the consumer.  When the consumer abandons the generator (close(), break, an exception in its loop body) every
-    worker - also one parked on the look-ahead throttle - leaves after the item it is working on: the throttle's
-    wait tests `exhausted` too (it did not: a consumer slower than the device that stopped early hung in join()).
+    worker - also one parked waiting for an item - leaves after the item it is working on.
 
-    `prefetch=True`: workers are called as fn(item, take_next); `take_next()` - callable once per item, never blocking -
-    claims the item this worker will get NEXT (or None: source dry, throttle full) so that the worker can start moving
-    it to the device while the current item is being processed (FaceService.process_stream: the upload of batch t+1
-    overlaps the kernels of batch t on the same lane)."""
+    The source is read by a FEEDER thread of its own, never by a worker: `next(batches)` may block for as long as the
+    source likes (a live camera sleeps for its fps limit, waits in cap.read and decodes: mixer.StreamMixer) and may itself
+    call into the service (a generator that enrols or looks up identities) - it runs outside every lock of this
+    pipeline and of the caller, and what it delivers waits in a queue of at most 2 x len(workers) items.
+
+    `prefetch=True`: workers are called as fn(item, take_next); `take_next()` - callable once per item, NEVER blocking:
+    it only takes an item the feeder has already delivered - claims the item this worker will get NEXT (or None:
+    nothing ready, source dry) so that the worker can start moving it to the device while the current item is being
+    processed (FaceService.process_stream: the upload of batch t+1 overlaps the kernels of batch t on the same lane).
+    A worker may therefore call it while holding locks of its own (the gallery's shared lock)."""
     it = iter(batches)
     n = len(workers)
     if n < 1:
         raise ValueError("run_ordered needs at least one worker")
     cv = threading.Condition()
-    st = {"next": 0, "yielded": 0, "done": {}, "exhausted": False, "error": None}
+    st = {"next": 0, "yielded": 0, "fed": 0, "done": {}, "ready": [], "src_done": False, "stopped": False, "error": None}
+
+    def feeder() -> None:
+        while True:
+            with cv:
+                while st["fed"] - st["yielded"] >= 2 * n and not st["stopped"] and st["error"] is None:
+                    cv.wait()
+                if st["stopped"] or st["error"] is not None:
+                    return
+            try:
+                item = next(it)                    # no lock held: the source may block, sleep or call back into the caller
+            except StopIteration:
+                with cv:
+                    st["src_done"] = True
+                    cv.notify_all()
+                return
+            except BaseException as ex:            # the caller's iterator failed: surface it in the consumer
+                with cv:
+                    st["error"] = ex
+                    cv.notify_all()
+                return
+            with cv:
+                st["ready"].append(item)
+                st["fed"] += 1
+                cv.notify_all()
 
     def claim(block: bool):
-        """(index, item) of the next source item, or None; call with cv held"""
-        while block and st["next"] - st["yielded"] >= 2 * n and st["error"] is None and not st["exhausted"]:
+        """(index, item) of the next delivered item, or None; call with cv held.  block=False returns at once."""
+        while block and not st["ready"] and not st["src_done"] and not st["stopped"] and st["error"] is None:
             cv.wait()
-        if st["exhausted"] or st["error"] is not None or (not block and st["next"] - st["yielded"] >= 2 * n):
+        if st["stopped"] or st["error"] is not None or not st["ready"]:
             return None
-        try:
-            item = next(it)
-        except StopIteration:
-            st["exhausted"] = True
-            cv.notify_all()
-            return None
-        except BaseException as ex:      # the caller's iterator failed: surface it in the consumer
-            st["error"] = ex
-            cv.notify_all()
-            return None
+        item = st["ready"].pop(0)
         t = st["next"]
         st["next"] += 1
         return t, item
@@ -95,14 +115,16 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
                 st["done"][t] = out
                 cv.notify_all()
 
+    feed = threading.Thread(target=feeder, daemon=True)
     threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]
+    feed.start()
     for th in threads:
         th.start()
     try:
         while True:
             with cv:
                 while (st["yielded"] not in st["done"] and st["error"] is None
-                       and not (st["exhausted"] and st["yielded"] >= st["next"])):
+                       and not (st["src_done"] and not st["ready"] and st["yielded"] >= st["next"])):
                     cv.wait()
                 if st["error"] is not None:
                     raise st["error"]
@@ -114,10 +136,11 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
             yield out
     finally:
         with cv:
-            st["exhausted"] = True       # consumer gone (or done): workers stop after their current item
+            st["stopped"] = True         # consumer gone (or done): workers stop after their current item
             cv.notify_all()
         for th in threads:
             th.join()
+        feed.join(timeout=0.2)           # a feeder parked inside a live source leaves with that source's next item (daemon)
 
 
 class Lanes:

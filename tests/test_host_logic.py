@@ -581,7 +581,7 @@ def test_run_ordered_prefetch_hands_every_item_to_exactly_one_worker_in_order():
     got = []
     for out in lanes_mod.run_ordered(src(40), [make(0), make(1)], prefetch=True):
         got.append(out)
-        assert len(pulled) - len(got) <= 4
+        assert len(pulled) - len(got) <= 5       # 2 x workers ahead of what the consumer has been HANDED (this item: not appended yet when the feeder pulled)
     assert got == [t * 10 for t in range(40)]
     assert sorted(t for t, _ in seen) == list(range(40)) and len({w for _, w in seen}) == 2
     assert staged_hits[0] >= 20                                            # most items arrived at their worker already staged
@@ -592,6 +592,51 @@ def test_run_ordered_prefetch_hands_every_item_to_exactly_one_worker_in_order():
     th.start()
     th.join(10)
     assert not th.is_alive()
+
+
+def test_run_ordered_slow_source_never_blocks_a_worker_or_its_locks():
+    """a LIVE source (a camera that sleeps for its fps limit and blocks in read: mixer.StreamMixer) is read by the
+    pipeline's feeder thread: take_next() returns at once whether or not the next batch exists, so a worker that calls it
+    while holding a lock (process_stream holds the gallery's shared lock there) never parks that lock on the source, a
+    batch's result is delivered before the source has produced the next one, and a source that takes an exclusive lock
+    of the caller's (a generator that enrols an identity) cannot deadlock against the workers' shared sections"""
+    import threading
+    import time
+    from frp_amd import lanes as lanes_mod
+    from frp_amd.gallery import Gallery
+    eng_ = FakeEngine()
+    G = Gallery(lambda: eng_)
+    waits, produced_at, delivered_at = [], {}, {}
+
+    def src(n):
+        for t in range(n):
+            time.sleep(0.15)                                   # fps limit / cap.read
+            with G.locked():                                   # the source enrols someone: exclusive gallery section
+                G.put(f"seen{t}", np.full(512, float(t + 1), np.float32))
+            produced_at[t] = time.perf_counter()
+            yield np.array([t])
+
+    def make():
+        def fn(item, take_next):
+            with G.reading():                                  # process_stream's guard around process + take_next + fetch
+                t0 = time.perf_counter()
+                take_next()
+                waits.append(time.perf_counter() - t0)
+                time.sleep(0.01)                               # the device pass
+            return int(item[0])
+        return fn
+
+    def run():
+        for out in lanes_mod.run_ordered(src(6), [make(), make()], prefetch=True):
+            delivered_at[out] = time.perf_counter()
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(20)
+    assert not th.is_alive(), "slow source + gallery writer deadlocked against the lanes' shared sections"
+    assert sorted(delivered_at) == list(range(6)) and len(G) == 6
+    assert max(waits) < 0.05, waits                            # never waited for the source (it sleeps 0.15 s per item)
+    for t in range(5):                                         # batch t is out before batch t + 1 even exists
+        assert delivered_at[t] < produced_at[t + 1], (t, delivered_at[t], produced_at[t + 1])
 
 
 def test_gallery_rw_lock_and_mirrors():
