@@ -111,6 +111,14 @@ __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16
 #define WN_PIECES 48       // patch-piece issue slots per workgroup and patch
 #define WN_ROWP_HALF 160   // row patches: (256 + 2 + 1) / 2 rows per half, rounded up to 32
 
+// Weight stage image (16 KiB per (channel block, kernel row, 16-channel slice); global memory holds the LDS image itself, so its
+// LDS-DMA is a linear copy): [frequency f: 4 KiB][32-cout block: 1 KiB][32 x 16-byte slots], slot (2 r + h) ^ ((r >> 3) & 1) of a
+// block = channels 8h .. 8h+7 of cout r.  A lane (r = lane & 31, h = lane >> 5) reads EVERY fragment of a stage at one per-lane
+// base + an immediate (f * 4096 + block * 1024): no address arithmetic in the k-loop.  The xor keeps a ds_read_b128's 16-lane
+// groups ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32) on 16 different 16-byte slots modulo 256 B: conflict-free.
+__host__ __device__ inline int wino_u_slot(int r, int h) { return (2 * r + h) ^ ((r >> 3) & 1); }
+__host__ __device__ inline int wino_u_lane(int r, int h) { return wino_u_slot(r, h) * 16; }
+
 // LDS rows of one half (even / odd pixels) of a super-patch: (256 + 2W + 2 + 1) / 2 rounded up to 32 (whole pieces per wave
 // for 4 and for 8 waves)
 __host__ __device__ inline int wino_half_rows(int W) { return ((WN_TP + 2 * W + 3) / 2 + 31) / 32 * 32; }
@@ -211,9 +219,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
         const int row = pair0 + b * 32 + fr_e + (i >> 1) + (ROWP ? 0 : kh * (p.W >> 1)) + (i & 1) * HALF;
         return row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
     };
-    int aoff[2];                               // weight fragment (cout block c, frequency f): chunk 2f + fh of row crow0 + 32c + fr
-#pragma unroll                                 // = the f = 0 address with bits 5..6 flipped by f (2f + fh = 2f ^ fh: no carry)
-    for (int c = 0; c < 2; ++c) aoff[c] = OFF_W + lds_off(crow0 + c * 32 + fr, fh);
+    // weight fragment (cout block c, frequency f) of a stage: wino_u_lane(fr, fh) + f * 4096 + (2 wave_c + c) * 1024 (see wino_u_lane)
+    const int aoff = OFF_W + wave_c * 2048 + wino_u_lane(fr, fh);
 
     floatx16 acc[4][PB][2];                    // [frequency][pair block][cout block]
     half8 raw[PB][4];                          // [pair block][position]: raw fragments of the NEXT sub-step
@@ -355,8 +362,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     auto read_u = [&](int slot, int f) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if constexpr (!(ABL & 2)) uf[f][c] = *reinterpret_cast<const half8*>(smem + (aoff[c] ^ (f << 5)) + slot * WN_WSLOT);
-            else asm volatile("" : "+v"(uf[f][c]) : "v"(aoff[c]));
+            if constexpr (!(ABL & 2)) uf[f][c] = *reinterpret_cast<const half8*>(smem + aoff + f * 4096 + c * 1024 + slot * WN_WSLOT);
+            else asm volatile("" : "+v"(uf[f][c]) : "v"(aoff));
         }
     };
     auto mfma_f = [&](int f, const half8 (&v)[PB]) {
@@ -492,6 +499,418 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
     stamp(p.stamps, 6);
 }
 
+
+// =====================================================================================================================
+// Second generation of the k-loop (round 4): the same tile, rings, arithmetic and epilogue - bit-identical results - with
+// the sub-step's instruction stream written out by hand.  What the compiler made of the first generation (ISA of round 3):
+// every fragment register was reused as soon as it was free, so four `s_waitcnt lgkmcnt(0)` per sub-step sat directly in
+// front of MFMAs whose operand had been requested one or two instructions earlier (the whole LDS latency exposed, in both
+// waves of a SIMD at the same time); per-read address arithmetic (xor per weight fragment); 12 spilled vector registers
+// and 75 scalar spills.  Here every instruction of the loop is a pinned `asm volatile` statement in the order below - the
+// compiler only allocates registers - and
+//   * ALL fragments of sub-step T + 1 (8 weight fragments, 4 raw pixel fragments) are requested during sub-step T, spread
+//     between its MFMAs, into registers that the MFMAs of T have already released: nothing an MFMA needs is ever
+//     younger than half a sub-step, the only LDS wait inside a sub-step is a counted one for the raw fragments before
+//     B^T d, and the sub-step after a barrier starts on operands that sit in registers;
+//   * weight fragments are read at ONE per-lane base + immediates (stage layout: wino_u_slot), raw fragments at
+//     per-kernel-row addresses kept in registers for a whole channel block;
+// Per sub-step and wave: 8 MFMAs, 12 ds_read_b128, 16 v_pk_add_f16, <= 3 xors, 2-3 LDS-DMA pieces, 3 waits, 1 barrier.
+// The weight ring runs THREE sub-steps ahead (stage T + 4 is issued in sub-step T, into the slot whose fragments sub-step T
+// itself computes on): with two, the late waves of a workgroup waited ~200 cycles for their own pieces in front of every
+// barrier (tools/wino_substep.py).  Write-after-read on the rings: every wave waits for ALL its fragment requests in front of
+// the barrier of sub-step T (lgkmcnt(0): they are the operands of T, requested during T - 1 from slot T & 3), so no read of
+// that slot is in flight anywhere when the DMA behind the barrier restages it; a patch slot is restaged one to five
+// sub-steps after the last read of it was consumed.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wn2_mfma(floatx16& acc, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ void wn2_read(half8& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// LDS-DMA piece (64 lanes x 16 B -> LDS m0v + lane * 16) from buffer `rsrc` at per-lane offset voff + scalar offset soff.
+// M0 is written in the statement that uses it (the compiler does not preserve it around asm).
+__device__ __forceinline__ void wn2_dma(const u32x4& rsrc, unsigned m0v, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void wn2_dma_global(unsigned m0v, const void* src) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory");
+}
+__device__ __forceinline__ void wn2_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wn2_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wn2_pk(unsigned& d, unsigned a, unsigned b) { asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void wn2_pk_sub(unsigned& d, unsigned a, unsigned b) {
+    asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ half8 wn2_add(const half8& a, const half8& b) {
+    WH8 x = __builtin_bit_cast(WH8, a), y = __builtin_bit_cast(WH8, b), r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wn2_pk(r.p[i], x.p[i], y.p[i]);
+    return __builtin_bit_cast(half8, r);
+}
+__device__ __forceinline__ half8 wn2_sub(const half8& a, const half8& b) {
+    WH8 x = __builtin_bit_cast(WH8, a), y = __builtin_bit_cast(WH8, b), r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wn2_pk_sub(r.p[i], x.p[i], y.p[i]);
+    return __builtin_bit_cast(half8, r);
+}
+template <int T> struct wn2_step_tag { static constexpr int value = T; };
+// lab build, VAR & 2: shader-clock stamps inside ONE sub-step (tools/wino_substep.py); s_memtime returns through lgkmcnt, out of
+// order with the LDS reads: the values are only read behind an lgkmcnt(0) at the end of the sampled sub-steps
+// (a result still in flight at the end of an asm statement may be copied - spilled to a vector lane - before it has arrived, and
+// eight 64-bit values in scalar registers did not survive the loop's scalar pressure: the stamp is waited for inside its
+// statement - so stamps are only placed where the wave's LDS queue is nearly empty anyway - and parked in two lanes of ONE
+// vector register)
+template <int SLOT>
+__device__ __forceinline__ void wn2_clock(unsigned& park) {
+    asm volatile("s_memtime vcc\n\ts_waitcnt lgkmcnt(0)\n\tv_writelane_b32 %0, vcc_lo, %1\n\tv_writelane_b32 %0, vcc_hi, %2" : "+v"(park) : "n"(2 * SLOT), "n"(2 * SLOT + 1) : "vcc");
+}
+
+template <int SLOT>
+__device__ __forceinline__ void wn2_clock_real(unsigned& park) {         // the constant 100 MHz clock next to it (in-kernel clock = ratio of the deltas)
+    asm volatile("s_memrealtime vcc\n\ts_waitcnt lgkmcnt(0)\n\tv_writelane_b32 %0, vcc_lo, %1\n\tv_writelane_b32 %0, vcc_hi, %2" : "+v"(park) : "n"(2 * SLOT), "n"(2 * SLOT + 1) : "vcc");
+}
+
+#define WN2_PPW 5            // patch pieces per wave and channel block (half_rows = 160 for every W <= 30: 40 row groups / 8 waves)
+                             // = the sub-steps of a block that carry patch pieces
+
+// VAR (lab build): 1 = waves 4-7 at s_setprio 1
+template <int VAR = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    ConvParams p = p_in;
+    constexpr int TP = WN_TP, TC = WN_TC;
+    constexpr int AHEAD = (VAR & 16) ? 2 : 3;  // sub-steps the weight ring runs ahead (lab: VAR & 16 = two)
+    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+        int n = *p.n_dev;
+        n = n < 0 ? 0 : (n > p.N ? p.N : n);
+        p.M = n * p.Ho * p.Wo;
+        p.n_ptiles = (p.M + TP - 1) / TP;
+    }
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n_tiles = p.n_ptiles * p.n_ctiles;
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {                // XCD-interleaved tile walk (see conv3x3_lean.hip)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = per;
+    } else {
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
+    if (t0 >= t1) return;
+    const int cpt = p.Cin >> 6;                // 64-channel blocks
+    const int cin2 = p.Cin * 2;                // bytes per pixel
+    const int HALF = wino_half_rows(p.W);      // 160 (launcher: 40 row groups of 8 rows per patch)
+    const int XSLOT = 2 * HALF * 128;
+    const int OFF_W = 2 * XSLOT;
+    const int OFF_Z = OFF_W + WN_NSW * WN_WSLOT;
+    const int OFF_PAR = OFF_Z + 256;
+    const int OFF_DUMP = OFF_PAR + 11 * TC * 4;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
+
+    // buffer descriptors as plain SGPR quads (asm operands): base, base_hi (stride 0), num_records, flags
+    const unsigned long xa = (unsigned long)p.x, wa = (unsigned long)p.w;
+    const u32x4 xrsrc = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const u32x4 wrsrc = {(unsigned)wa, (unsigned)(wa >> 32) & 0xffffu, p.w_bytes, 0x00020000u};
+
+    // ---------------- DMA lane geometry (as the first generation): a piece fills 8 LDS rows x 128 B, lane -> row lane / 8,
+    // 16-byte position lane % 8 holding logical chunk pos ^ ((row >> 1) & 7) (source-side swizzle)
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+    const int xlane = (2 * lrow - p.W - 1) * cin2 + lchunk * 16;
+    // patch piece j of this wave = LDS row group wave + 8 j; rows below HALF hold the even pixel offsets r = 2 row, the
+    // others r = 2 (row - HALF) + 1 of the super-patch; its scalar source offset (added to the per-lane part per piece)
+    // VAR & 8 (lab): only waves 0-3 - the older wave of every SIMD, which reaches the barrier ~170 cycles before its partner -
+    // issue the DMA stream (twice the pieces each): NDW issuing waves, XPW patch / WPW weight pieces per issuing wave
+    constexpr bool HALF_DMA = (VAR & 8) != 0;
+    constexpr int NDW = HALF_DMA ? 4 : 8, XPW = 40 / NDW, WPW = 16 / NDW, XPS = XPW / 5;
+    const bool dma_wave = !HALF_DMA || wave < 4;
+    int sxo[XPW];
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        const int row0 = (wave + NDW * j) * 8;
+        sxo[j] = (row0 < HALF ? 2 * row0 : 2 * (row0 - HALF) + 1) * cin2;
+    }
+    constexpr int DEAD = (int)0x80000000;
+
+    // ---------------- consumer geometry: wave (wp, wc) owns pairs [32 wp, +32) x couts [64 wc, +64) of the tile
+    const int wave_p = wave >> 1, wave_c = wave & 1;
+    const int pair0 = wave_p * 32, crow0 = wave_c * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+    int fr_e = fr, fh_e = fh, lane_e = lane;   // copies made opaque per tile (address arithmetic stays where it is used: hoisted out of
+                                               // the tile loop it is spilled at kernel start and reloaded in every epilogue)
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    const unsigned ubase = lds0 + OFF_W + wave_c * 2048 + wino_u_lane(fr, fh);
+    // raw fragment (position i = 0..3, kernel row kh): LDS row pair + (i >> 1) + kh W/2 + (i & 1) HALF of a patch slot;
+    // byte address of its kk = 0 fragment (kk flips address bits 5..6); lanes whose tap falls off the image (or whose pair
+    // does not exist) read a 256-byte zero block at the bank offset their real address would have had
+    auto raw_addr = [&](unsigned mask, int kh, int i, int xslot) -> unsigned {
+        const int row = pair0 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+        const int a_ = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+        const bool rowok = (mask & 1u) && (kh == 0 ? (mask & 2u) : kh == 2 ? (mask & 4u) : true);
+        const bool ok = rowok && (i == 0 ? (mask & 8u) : i == 3 ? (mask & 16u) : true);
+        return lds0 + (ok ? xslot + a_ : OFF_Z + (a_ & 255));
+    };
+
+    floatx16 acc[4][2];                        // [frequency][cout block]
+    half8 U[2][8];                             // [sub-step parity][frequency * 2 + cout block]: weight fragments
+    half8 V[2][4];                             // [sub-step parity][frequency]: B^T d
+    half8 raw[4];                              // raw pixel fragments of the next sub-step (dead after B^T d)
+
+    float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
+    float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
+    const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
+    // epilogue parameters of a tile (bias classes + slopes, 5 KiB): one LDS-DMA piece per wave with per-lane global addresses
+    auto dma_params = [&](int tile) {
+        const int c0p = (tile % p.n_ctiles) * TC;
+        const int o = wave * 1024 + lane_e * 16;
+        const char* src = reinterpret_cast<const char*>(p.bias);
+        if (o < 9 * TC * 4) {
+            const int cls = border ? o / (TC * 4) : 0;
+            int co = c0p + ((o % (TC * 4)) >> 2);
+            co = co + 4 <= p.Cout ? co : 0;
+            src = reinterpret_cast<const char*>(p.bias + (long)cls * p.Cout + co);
+        } else if (o < 10 * TC * 4 && p.slope) {
+            int co = c0p + ((o - 9 * TC * 4) >> 2);
+            co = co + 4 <= p.Cout ? co : 0;
+            src = reinterpret_cast<const char*>(p.slope + co);
+        }
+        wn2_dma_global(lds0 + (wave < 5 ? OFF_PAR + wave * 1024 : OFF_DUMP + wave * 1024), src);
+    };
+
+    struct Tile { int m0b; int wbase; unsigned vmask; };
+    // vmask: validity bits of this lane's pair: 1 pair exists, 2 row above inside, 4 row below inside, 8 left neighbour (d0)
+    // inside, 16 right neighbour (d3) inside
+    auto make_tile = [&](int tile, Tile& d) {
+        if (tile >= t1) { d.m0b = DEAD; d.wbase = DEAD; d.vmask = 0; return; }
+        const int pt = tile / p.n_ctiles;
+        const int ct_ = tile - pt * p.n_ctiles;
+        d.m0b = pt * TP * cin2;
+        d.wbase = ct_ * cpt * 12 * WN_WSLOT;
+        const int m = pt * TP + 2 * (pair0 + fr_e);
+        unsigned mask = 0;
+        if (m < p.M) {
+            int n, rem, oy, ox;
+            fast_divmod(m, HoWo, inv_howo, n, rem);
+            fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+            mask = 1u | (oy > 0 ? 2u : 0u) | (oy < p.H - 1 ? 4u : 0u) | (ox > 0 ? 8u : 0u) | (ox + 2 < p.W ? 16u : 0u);
+        }
+        d.vmask = mask;
+    };
+
+    // ---------------- prologue: patch of the first tile's first channel block, weight stages 0..3
+    unsigned clkk = 0;                         // (lab, VAR & 2: shader clock and 100 MHz clock at kernel start / end in its lanes 8..15)
+    if constexpr (VAR & 2) { if (p.stamps && blockIdx.x < 32) { wn2_clock<4>(clkk); wn2_clock_real<5>(clkk); } }
+    else stamp(p.stamps, 0);
+    if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
+    Tile cur, nt;
+    make_tile(t0, cur);
+    {
+        const unsigned xb0 = (unsigned)(cur.m0b + xlane);
+        if (dma_wave) {
+#pragma unroll
+            for (int j = 0; j < XPW; ++j) wn2_dma(xrsrc, lds0 + (wave + NDW * j) * 1024, xb0 + sxo[j], 0u);
+#pragma unroll
+            for (int st = 0; st < (AHEAD + 1); ++st)
+#pragma unroll
+                for (int j = 0; j < WPW; ++j)
+                    wn2_dma(wrsrc, lds0 + OFF_W + st * WN_WSLOT + (wave + NDW * j) * 1024, (unsigned)(lane * 16),
+                            (unsigned)(cur.wbase + st * WN_WSLOT + (wave + NDW * j) * 1024));
+        }
+    }
+    int xs = 0;                                // byte offset of the patch slot the running channel block reads
+    const bool has_res = p.res != nullptr;
+    if constexpr (VAR & 1) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+
+    // first sub-step's operands of a tile (its patch in slot `xslot`, weight stage 0 in ring slot 0): plain loads, waited for by the
+    // compiler; every later sub-step's operands are requested one sub-step ahead inside the loop
+    auto first_operands = [&](const Tile& tl, int xslot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const half8*>(smem + (raw_addr(tl.vmask, 0, i, xslot) - lds0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) U[0][e] = *reinterpret_cast<const half8*>(smem + (ubase - lds0) + (e >> 1) * 4096 + (e & 1) * 1024);
+        V[0][0] = wn2_sub(raw[0], raw[2]);
+        V[0][1] = wn2_add(raw[1], raw[2]);
+        V[0][2] = wn2_sub(raw[2], raw[1]);
+        V[0][3] = wn2_sub(raw[1], raw[3]);
+    };
+    wait_vmcnt<AHEAD * WPW>();              // patch and stage 0 are in
+    __syncthreads();
+    first_operands(cur, 0);
+    if constexpr (!(VAR & 2)) stamp(p.stamps, 1);
+
+    for (int ct = t0; ct < t1; ct += tstep) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[f][c][e] = 0.f;
+        const int ptile = ct / p.n_ctiles;
+        const int m0 = ptile * TP;
+        const int c0 = (ct - ptile * p.n_ctiles) * TC;
+        make_tile(ct + tstep, nt);
+        asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(lane_e));
+        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 2); }
+
+        for (int cb = 0; cb < cpt; ++cb) {
+            const bool last_cb = cb + 1 == cpt;
+            // what lies beyond this channel block: the next block of this tile, or block 0 of the next tile
+            const int nxm0b = last_cb ? nt.m0b : cur.m0b;
+            const int nxw = last_cb ? nt.wbase : cur.wbase;
+            // per-block operands of the pinned statements (fr_e opaque per block: hoisted out of the loop, both patch slots' variants
+            // of the 16 addresses cost 28 registers and spilled)
+            asm volatile("" : "+v"(fr_e));
+            unsigned radr[3][4], rnx[4];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) radr[kh][i] = raw_addr(cur.vmask, kh, i, xs);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rnx[i] = raw_addr(last_cb ? nt.vmask : cur.vmask, 0, i, xs ^ XSLOT);
+            const unsigned xb = nxm0b == DEAD ? 0x80000000u : (unsigned)(nxm0b + (last_cb ? 0 : (cb + 1) << 7) + xlane);
+            const unsigned lx = lds0 + (xs ^ XSLOT) + wave * 1024;          // next patch: row group wave (+ NDW j)
+            const unsigned lw = lds0 + OFF_W + wave * 1024;                 // weight ring: piece wave (+ NDW j) of a slot
+            const unsigned wsa = (unsigned)(cur.wbase + cb * 12 * WN_WSLOT + wave * 1024);
+            const unsigned wsb = nxw == DEAD ? 0u : (unsigned)(nxw + (last_cb ? 0 : (cb + 1) * 12) * WN_WSLOT + wave * 1024);
+            const unsigned wva = (unsigned)(lane * 16);
+            const unsigned wvb = nxw == DEAD ? CONV_OOB : (unsigned)(lane * 16);
+
+            // One sub-step T = kh * 4 + kk (everything static but the operands above).  U[T & 1], V[T & 1] hold its operands.
+            // In front of its barrier: weight stage T + 1 has landed (issued two sub-steps ago; behind it in the in-order counter
+            // only the pieces of sub-step T - 1: 2 weight pieces, + 1 patch piece if (T - 1) mod 12 <= 4).
+            unsigned clk = 0;                   // (lab: 8 stamps x 2 dwords in its lanes 0..15)
+            const bool sample = (VAR & 2) && p.stamps && blockIdx.x < 32 && ct == t0 && cb == (cpt > 1 ? 1 : 0);
+            auto step = [&](auto tag) {
+                constexpr int T = decltype(tag)::value;
+                constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;
+                constexpr int P = T & 1, Q = P ^ 1;
+                constexpr int SLN = (T + 1) & 3;                               // ring slot of stage T + 1
+                constexpr int SLD = (T + AHEAD + 1) & 3;                       // ring slot stage T + AHEAD + 1 goes to (three ahead: the one this
+                                                                               // sub-step's own operands came from, all in registers by now)
+                constexpr int TS = T + AHEAD + 1;                              // ... of this block, or stage TS - 12 of what lies beyond it
+                auto w_piece = [&](int j) {
+                    if (!dma_wave) return;
+                    if constexpr (TS < 12) wn2_dma(wrsrc, lw + SLD * WN_WSLOT + j * NDW * 1024, wva, wsa + TS * WN_WSLOT + j * NDW * 1024);
+                    else wn2_dma(wrsrc, lw + SLD * WN_WSLOT + j * NDW * 1024, wvb, wsb + (TS - 12) * WN_WSLOT + j * NDW * 1024);
+                };
+                auto x_piece = [&](int q) {                                    // the next channel block's patch
+                    if constexpr (T < 5) { if (dma_wave) wn2_dma(xrsrc, lx + (XPS * T + q) * NDW * 1024, xb + sxo[XPS * T + q], 0u); }
+                };
+                if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<0>(clk); }
+                // stage T + 1 has landed: issued in sub-step T - 3; younger than its pieces are the patch piece of T - 3 and the
+                // pieces of T - 2 and T - 1 (2 weight pieces each, + 1 patch piece in sub-steps 0..4 of a block)
+                // (per issuing wave: WPW weight pieces per sub-step, XPS patch pieces in each of sub-steps 0..4 of a block; with two
+                // sub-steps of lead the pieces of T - 1 only)
+                constexpr int VMC = AHEAD == 3 ? 2 * WPW + XPS * (((T + 9) % 12 < 5) + ((T + 10) % 12 < 5) + ((T + 11) % 12 < 5))
+                                               : WPW + XPS * ((T + 11) % 12 < 5);
+                wait_vmcnt<VMC>();
+                // every fragment requested so far is in (the operands of this sub-step, requested during T - 1): behind the barrier
+                // another wave restages the slot they came from
+                wn2_wait_lgkm<0>();
+                if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<1>(clk); }
+                wn2_barrier();
+                if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<2>(clk); }
+                if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(3);         // (lab) the wave that is behind in its sub-step wins the issue arbitration
+                wn2_mfma(acc[0][0], U[P][0], V[P][0]);
+                if constexpr (T == 0) { if (cb == 0) dma_params(ct); }         // (visible from the barrier of sub-step 2 on; the previous
+                                                                               //  tile's epilogue, the last reader, lies before this barrier)
+                // (T = 11 of a tile's last channel block requests the next tile's first operands like any other sub-step, but nothing is
+                // KEPT across the epilogue: fragments held there - 48 registers, or 24 for B^T d and two weight fragments - spilled
+                // in it and cost more than requesting them again behind it; the dead requests cost nothing)
+                {
+                    const unsigned a0 = T == 11 ? rnx[0] : radr[KHN][0] ^ (KKN << 5), a1 = T == 11 ? rnx[1] : radr[KHN][1] ^ (KKN << 5);
+                    wn2_read<0>(raw[0], a0);
+                    wn2_read<0>(raw[1], a1);
+                }
+                wn2_mfma(acc[0][1], U[P][1], V[P][0]);
+                {
+                    const unsigned a2 = T == 11 ? rnx[2] : radr[KHN][2] ^ (KKN << 5), a3 = T == 11 ? rnx[3] : radr[KHN][3] ^ (KKN << 5);
+                    wn2_read<0>(raw[2], a2);
+                    wn2_read<0>(raw[3], a3);
+                }
+                w_piece(0);
+                if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(2);
+                wn2_mfma(acc[1][0], U[P][2], V[P][1]);
+                wn2_read<SLN * WN_WSLOT + 0 * 4096 + 0>(U[Q][0], ubase);
+                wn2_read<SLN * WN_WSLOT + 0 * 4096 + 1024>(U[Q][1], ubase);
+                w_piece(1);
+                wn2_mfma(acc[1][1], U[P][3], V[P][1]);
+                wn2_read<SLN * WN_WSLOT + 1 * 4096 + 0>(U[Q][2], ubase);
+                wn2_read<SLN * WN_WSLOT + 1 * 4096 + 1024>(U[Q][3], ubase);
+                if constexpr (HALF_DMA) w_piece(2);
+                x_piece(0);
+                if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(1);
+                wn2_mfma(acc[2][0], U[P][4], V[P][2]);
+                wn2_read<SLN * WN_WSLOT + 2 * 4096 + 0>(U[Q][4], ubase);
+                wn2_read<SLN * WN_WSLOT + 2 * 4096 + 1024>(U[Q][5], ubase);
+                wn2_wait_lgkm<6>();                                            // the four raw fragments are in
+                if constexpr (HALF_DMA) w_piece(3);
+                V[Q][0] = wn2_sub(raw[0], raw[2]);                             // B^T d: V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
+                V[Q][1] = wn2_add(raw[1], raw[2]);
+                wn2_mfma(acc[2][1], U[P][5], V[P][2]);
+                if constexpr (HALF_DMA) x_piece(1);
+                wn2_read<SLN * WN_WSLOT + 3 * 4096 + 0>(U[Q][6], ubase);
+                wn2_read<SLN * WN_WSLOT + 3 * 4096 + 1024>(U[Q][7], ubase);
+                V[Q][2] = wn2_sub(raw[2], raw[1]);
+                if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(0);
+                wn2_mfma(acc[3][0], U[P][6], V[P][3]);
+                V[Q][3] = wn2_sub(raw[1], raw[3]);
+                wn2_mfma(acc[3][1], U[P][7], V[P][3]);
+                if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<3>(clk); }          // end of sub-step 6
+                if constexpr ((VAR & 2) && T == 11) {
+                    if (sample && lane < 8) reinterpret_cast<unsigned*>(p.stamps)[((long)blockIdx.x * 8 + wave) * 16 + lane] = clk;
+                }
+            };
+            step(wn2_step_tag<0>{}); step(wn2_step_tag<1>{}); step(wn2_step_tag<2>{}); step(wn2_step_tag<3>{});
+            step(wn2_step_tag<4>{}); step(wn2_step_tag<5>{}); step(wn2_step_tag<6>{}); step(wn2_step_tag<7>{});
+            step(wn2_step_tag<8>{}); step(wn2_step_tag<9>{}); step(wn2_step_tag<10>{}); step(wn2_step_tag<11>{});
+            wn2_wait_lgkm<0>();                // every request of the block has landed: the compiler may move the registers now
+            xs ^= XSLOT;
+        }
+
+        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 4); }
+        // the epilogue reads the accumulators with vector instructions: the last MFMAs must have left the matrix pipe (the
+        // compiler pads what it schedules itself, not what sits in asm statements)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                     "+v"(acc[3][0]), "+v"(acc[3][1]));
+        {
+            floatx16 (&acc4)[4][1][2] = *reinterpret_cast<floatx16 (*)[4][1][2]>(&acc);
+#define WN_EPI(FULL_, ACT_, RES_) \
+    wino_tile_epilogue<1, FULL_, ACT_, RES_>(p, acc4, lds_bias, lds_slope, m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo)
+            const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
+            if (!full) WN_EPI(false, -1, -1);
+            else if (p.act == FRP_ACT_PRELU) { if (has_res) WN_EPI(true, FRP_ACT_PRELU, 1); else WN_EPI(true, FRP_ACT_PRELU, 0); }
+            else if (p.act == FRP_ACT_RELU) { if (has_res) WN_EPI(true, FRP_ACT_RELU, 1); else WN_EPI(true, FRP_ACT_RELU, 0); }
+            else { if (has_res) WN_EPI(true, FRP_ACT_NONE, 1); else WN_EPI(true, FRP_ACT_NONE, 0); }
+#undef WN_EPI
+        }
+        cur = nt;
+        if (ct + tstep < t1) first_operands(cur, xs);       // (its patch and stage 0 landed before this tile's last barrier)
+        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 5); }
+    }
+    // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
+    wait_vmcnt<0>();
+    if constexpr (VAR & 2) {
+        if (p.stamps && blockIdx.x < 32) {
+            wn2_clock<6>(clkk);
+            wn2_clock_real<7>(clkk);
+            if (lane >= 8 && lane < 16) reinterpret_cast<unsigned*>(p.stamps)[((long)blockIdx.x * 8 + wave) * 16 + lane] = clkk;
+        }
+    } else stamp(p.stamps, 6);
+}
+
 // Shapes the Winograd kernel covers; `p` carries the derived fields of launch_conv().
 bool conv3x3_wino_eligible(const ConvParams& p) {
     if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
@@ -542,8 +961,46 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int VAR>
+static hipError_t launch_wino2_cfg(const ConvParams& p0, hipStream_t stream) {
+    ConvParams p = p0;
+    p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
+    p.n_ctiles = (p.Cout + WN_TC - 1) / WN_TC;
+    const size_t img = conv3x3_wino_image_bytes(p.Cin, p.Cout);
+    if (img >= 0x7fffffffUL) return hipErrorInvalidValue;
+    p.w_bytes = (unsigned)img;
+    if (wino_half_rows(p.W) != WN2_PPW * 32) return hipErrorInvalidValue;          // 5 patch pieces per wave
+    const int lds = wino_lds_bytes(p.W);
+    static int attr_lds[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_lds[dev] < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((conv3x3_wino2_kernel<VAR>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_lds[dev] = 160 * 1024;
+    }
+    const long ntiles = (long)p.n_ptiles * p.n_ctiles;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    const int ncu = device_cu_count(dev);
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);     // persistent: one workgroup per CU
+    hipLaunchKernelGGL((conv3x3_wino2_kernel<VAR>), dim3(grid), dim3(512), lds, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     if (!conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
+#ifdef FRP_LAB   // dbg bit 128: the first generation of the k-loop (compiler-scheduled; A/B partner of the hand-ordered one)
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 13) return launch_wino2_cfg<2>(p, stream);   // sub-step stamps
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 14) return launch_wino2_cfg<1>(p, stream);   // waves 4-7 at priority 1
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 12) return launch_wino2_cfg<4>(p, stream);   // priority falls with progress
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 11) return launch_wino2_cfg<8>(p, stream);   // DMA by waves 0-3 only
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 10) return launch_wino2_cfg<16>(p, stream);  // ring two ahead
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 9) return launch_wino2_cfg<9>(p, stream);    // DMA by waves 0-3, waves 4-7 at priority 1
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && !((p.dbg >> 1) & 15)) return launch_wino2_cfg<0>(p, stream);
+#else
+    return wino_super_patch(p.W) ? launch_wino2_cfg<0>(p, stream) : hipErrorInvalidValue;
+#endif
 #ifdef FRP_LAB   // dbg bit 32: the one-wave-per-SIMD configuration (A/B runs in the lab build; 0.7 x the speed of the default)
     if ((p.dbg & 32) && wino_super_patch(p.W)) return launch_wino_cfg<4>(p, stream);
     if (wino_super_patch(p.W)) switch ((p.dbg >> 1) & 15) {               // dbg bits 1..4: timing ablations (tools/wino_ablate.py)

@@ -193,9 +193,10 @@ float f16_bits_to_f32(uint16_t hbits) {
 }
 
 // Weight image of the Winograd kernel (conv3x3_wino.hip) from folded fp16 weights [Cout][3][3][Cin]: per (cout tile of
-// 128, 64-channel block, kernel row, 16-channel slice) one 16 KiB stage = the LDS image itself: 128 rows (couts; rows
-// beyond Cout zero) x 8 chunks of 16 B, logical chunk 2f + h = frequency f, 8-channel half h, stored at position
-// chunk ^ ((row >> 1) & 7).  U = G g: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 - exact in fp32 on fp16 inputs, rounded once.
+// 128, 64-channel block, kernel row, 16-channel slice) one 16 KiB stage = the LDS image itself: [frequency f][32-cout block]
+// [32 x 16-byte slots] (couts beyond Cout zero), the 8-channel half h of cout r of a block at slot (2 r + h) ^ ((r >> 3) & 1):
+// every fragment of a stage is one per-lane base + an immediate (conv3x3_wino.hip: wino_u_slot).  U = G g: g0, (g0+g1+g2)/2,
+// (g0-g1+g2)/2, g2 - exact in fp32 on fp16 inputs, rounded once.
 void build_wino_image(const uint16_t* w16, int Cin, int Cout, uint16_t* img) {
     const int cpt = Cin / 64, nct = (Cout + 127) / 128;
     for (int ct = 0; ct < nct; ++ct)
@@ -212,10 +213,9 @@ void build_wino_image(const uint16_t* w16, int Cin, int Cout, uint16_t* img) {
                                 if (co < Cout)
                                     for (int kw = 0; kw < 3; ++kw) g[kw] = f16_bits_to_f32(w16[(((size_t)co * 3 + kh) * 3 + kw) * Cin + ci]);
                                 const float u[4] = {g[0], (g[0] + g[1] + g[2]) * 0.5f, (g[0] - g[1] + g[2]) * 0.5f, g[2]};
-                                for (int f = 0; f < 4; ++f) {
-                                    const int chunk = (2 * f + hh) ^ ((row >> 1) & 7);
-                                    st[row * 64 + chunk * 8 + e] = f32_to_f16_bits(u[f]);
-                                }
+                                // stage layout (conv3x3_wino.hip: wino_u_slot): [f][32-cout block][slot (2 r + h) ^ ((r >> 3) & 1)][8 channels]
+                                const int r = row & 31, slot = (2 * r + hh) ^ ((r >> 3) & 1);
+                                for (int f = 0; f < 4; ++f) st[f * 2048 + (row >> 5) * 512 + slot * 8 + e] = f32_to_f16_bits(u[f]);
                             }
                     }
                 }

@@ -32,19 +32,23 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     tot = [0.0, 0.0, 0.0]
     for name, N, H, W, Ci, Co, act, fl, res in SHAPES:
-        best = [1e30, 1e30, 1e30]
+        variants = [0, 0x10000, 0x10000 | (128 << 8)] + [0x10000 | ((int(x) << 1) << 8) for x in os.environ.get("WINO_VARIANTS", "").split(",") if x]
+        best = [1e30] * len(variants)
         for _ in range(3):
-            for v, extra in enumerate((0, 0x10000, 0x10000 | (32 << 8))):     # direct, Winograd 2 waves per SIMD, 1 wave per SIMD
-                if v == 2 and W > 30:                                          # (one wave per SIMD exists for the super-patch form only)
+            # direct, Winograd (hand-ordered k-loop, round 4), Winograd first generation (compiler-scheduled k-loop: dbg bit 128),
+            # + lab variants of the hand-ordered loop (WINO_VARIANTS=14,12: dbg codes)
+            for v, extra in enumerate(variants):
+                if v >= 2 and W > 30:                                          # (wide maps: the row-patch form is first generation anyway)
                     best[v] = float("nan")
                     continue
                 best[v] = min(best[v], eng.conv_bench(N, H, W, Ci, Co, 3, 1, act, fl | extra, res, iters) * 1e3)
         fl_ = 2.0 * N * H * W * 9 * Ci * Co
-        for v in range(3):
+        tot = tot + [0.0] * (len(best) - len(tot))
+        for v in range(len(best)):
             tot[v] += best[v]
-        print(f"{name:58s} direct {best[0]:7.1f} us {fl_ / best[0] / 1e6:7.1f} TF | winograd 8 waves {best[1]:7.1f} us {fl_ / best[1] / 1e6:7.1f} TF eff "
-              f"x{best[0] / best[1]:.3f} | 4 waves {best[2]:7.1f} us x{best[0] / best[2]:.3f}")
-    print(f"sum direct {tot[0]:.1f} us, winograd 8 waves {tot[1]:.1f} us x{tot[0] / tot[1]:.3f}, 4 waves {tot[2]:.1f} us x{tot[0] / tot[2]:.3f}")
+        print(f"{name:58s} direct {best[0]:7.1f} us {fl_ / best[0] / 1e6:7.1f} TF | winograd {best[1]:7.1f} us {fl_ / best[1] / 1e6:7.1f} TF eff "
+              f"x{best[0] / best[1]:.3f} | first generation {best[2]:7.1f} us x{best[0] / best[2]:.3f}" + "".join(f" | var {best[v]:7.1f}" for v in range(3, len(best))), flush=True)
+    print(f"sum direct {tot[0]:.1f} us, winograd {tot[1]:.1f} us x{tot[0] / tot[1]:.3f}, first generation {tot[2]:.1f} us x{tot[0] / tot[2]:.3f}" + "".join(f", var {t:.1f}" for t in tot[3:]))
 
 
 if __name__ == "__main__":
