@@ -95,6 +95,9 @@ struct frp_handle {
     DevBuf gallery;
     int64_t g_rows = 0;
     DevBuf g_reserved;               // frp_gallery_reserve: filled by the caller, swapped in by frp_gallery_commit
+    // exact compat rows (frp_gallery_exact): float64 [g_rows x 512] as enrolled, next to the unit fp16 snapshot
+    bool g_exact = false;
+    DevBuf gx, gx_q, gx_out;
     // profiling
     hipEvent_t ev[EV_COUNT]{};
     frp_counters ctr{};
@@ -927,6 +930,34 @@ int upload_rows_normalized(frp_handle* h, const float* rows, int64_t n, _Float16
     return FRP_OK;
 }
 
+// exact compat rows: `n` host rows of `d` = 512 values of `dtype` -> float64 at dst (device row pointer)
+int upload_rows_exact(frp_handle* h, const void* emb, int64_t n, int dtype, double* dst) {
+    if (n <= 0) return FRP_OK;
+    const size_t cnt = (size_t)n * FRP_EMB_DIM;
+    std::vector<double> tmp;
+    const double* src = (const double*)emb;
+    if (dtype != FRP_F64) {
+        tmp.resize(cnt);
+        if (dtype == FRP_F32) { const float* f = (const float*)emb; for (size_t i = 0; i < cnt; ++i) tmp[i] = (double)f[i]; }
+        else if (dtype == FRP_F16) { const uint16_t* u = (const uint16_t*)emb; for (size_t i = 0; i < cnt; ++i) tmp[i] = (double)f16_bits_to_f32(u[i]); }
+        else return fail(h, FRP_ERR_INVALID, "bad dtype");
+        src = tmp.data();
+    }
+    HIPCHK(h, hipMemcpyAsync(dst, src, cnt * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // (tmp / the caller's rows go away)
+    return FRP_OK;
+}
+
+// a fresh exact matrix of `n` rows widened from unit fp16 device rows (rows installed from device data, or that existed before)
+int exact_from_f16(frp_handle* h, const void* dev_f16, int64_t n, DevBuf& fresh) {
+    if (n <= 0) return FRP_OK;
+    FRPCHK(ensure(h, fresh, (size_t)n * FRP_EMB_DIM * 8));
+    hipError_t e = launch_gallery_widen((const _Float16*)dev_f16, (double*)fresh.p, n, FRP_EMB_DIM, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("gallery_widen: ") + hipGetErrorString(e)); }
+    return FRP_OK;
+}
+
 struct Guard {
     std::lock_guard<std::mutex> lk;
     explicit Guard(frp_handle* h, bool settle = true) : lk(h->mu) {
@@ -994,7 +1025,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
                      &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery,
-                     &h->g_reserved};
+                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
@@ -1156,18 +1187,24 @@ int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_
     Guard g(h);
     release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
     if (n < 0 || (n > 0 && !emb) || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512]");
-    DevBuf fresh;   // new snapshot, swapped in when complete
+    DevBuf fresh, fresh_x;   // new snapshot(s), swapped in when complete
     if (n > 0) {
         std::vector<float> f;
         const float* rows = (const float*)emb;
         if (dtype != FRP_F32) { FRPCHK(to_f32(h, emb, (size_t)n * d, dtype, f)); rows = f.data(); }
         FRPCHK(ensure(h, fresh, (size_t)n * d * 2));
         int r = upload_rows_normalized(h, rows, n, (_Float16*)fresh.p);
-        if (r != FRP_OK) { release(fresh); return r; }
+        if (r == FRP_OK && h->g_exact) {
+            r = ensure(h, fresh_x, (size_t)n * d * 8);
+            if (r == FRP_OK) r = upload_rows_exact(h, emb, n, dtype, (double*)fresh_x.p);
+        }
+        if (r != FRP_OK) { release(fresh); release(fresh_x); return r; }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     release(h->gallery);
     h->gallery = fresh;
+    release(h->gx);
+    h->gx = fresh_x;
     h->g_rows = n;
     return FRP_OK;
 }
@@ -1182,8 +1219,12 @@ int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_
     hipError_t e = hipMemcpyAsync(fresh.p, dev_f16, (size_t)n * d * 2, hipMemcpyDeviceToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("gallery copy: ") + hipGetErrorString(e)); }
+    DevBuf fresh_x;
+    if (h->g_exact) { int r = exact_from_f16(h, fresh.p, n, fresh_x); if (r != FRP_OK) { release(fresh); return r; } }
     release(h->gallery);
     h->gallery = fresh;
+    release(h->gx);
+    h->gx = fresh_x;
     h->g_rows = n;
     return FRP_OK;
 }
@@ -1204,9 +1245,13 @@ int frp_gallery_commit(frp_handle* h, int64_t n_rows) {
     if (!h->g_reserved.p || n_rows < 0 || (size_t)n_rows * FRP_EMB_DIM * 2 > h->g_reserved.cap)
         return fail(h, FRP_ERR_INVALID, "gallery commit without a matching reservation");
     HIPCHK(h, hipStreamSynchronize(h->stream));      // nothing of this handle still reads the old snapshot
+    DevBuf fresh_x;
+    if (h->g_exact) FRPCHK(exact_from_f16(h, h->g_reserved.p, n_rows, fresh_x));
     release(h->gallery);
     h->gallery = h->g_reserved;
     h->g_reserved = DevBuf();
+    release(h->gx);
+    h->gx = fresh_x;
     h->g_rows = n_rows;
     return FRP_OK;
 }
@@ -1237,7 +1282,20 @@ int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t 
         release(h->gallery);
         h->gallery = fresh;
     }
+    if (h->g_exact && (size_t)(row + 1) * d * 8 > h->gx.cap) {        // the exact copy grows with the snapshot's row capacity
+        DevBuf fresh;
+        const size_t cap_rows = std::max<size_t>(h->gallery.cap / ((size_t)d * 2), (size_t)row + 1);
+        FRPCHK(ensure(h, fresh, cap_rows * d * 8));
+        if (h->g_rows > 0) {
+            hipError_t e = hipMemcpyAsync(fresh.p, h->gx.p, (size_t)h->g_rows * d * 8, hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("exact gallery grow: ") + hipGetErrorString(e)); }
+        }
+        release(h->gx);
+        h->gx = fresh;
+    }
     FRPCHK(upload_rows_normalized(h, f.data(), 1, (_Float16*)h->gallery.p + row * d));
+    if (h->g_exact) FRPCHK(upload_rows_exact(h, emb, 1, dtype, (double*)h->gx.p + row * d));
     if (row == h->g_rows) h->g_rows += 1;
     return FRP_OK;
 }
@@ -1251,6 +1309,9 @@ int frp_gallery_remove_row(frp_handle* h, int64_t row) {
     if (row != last) {
         HIPCHK(h, hipMemcpyAsync((_Float16*)h->gallery.p + row * FRP_EMB_DIM, (_Float16*)h->gallery.p + last * FRP_EMB_DIM,
                                  FRP_EMB_DIM * 2, hipMemcpyDeviceToDevice, h->stream));
+        if (h->g_exact)
+            HIPCHK(h, hipMemcpyAsync((double*)h->gx.p + row * FRP_EMB_DIM, (double*)h->gx.p + last * FRP_EMB_DIM, FRP_EMB_DIM * 8,
+                                     hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     h->g_rows = last;
@@ -1266,6 +1327,58 @@ int frp_gallery_get(frp_handle* h, void* out_f16, int64_t first_row, int64_t n_r
     if (n_rows == 0) return FRP_OK;
     HIPCHK(h, hipMemcpyAsync(out_f16, (_Float16*)h->gallery.p + first_row * FRP_EMB_DIM, (size_t)n_rows * FRP_EMB_DIM * 2,
                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_gallery_exact(frp_handle* h, int32_t on) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!on) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        release(h->gx); release(h->gx_q); release(h->gx_out);
+        h->g_exact = false;
+        return FRP_OK;
+    }
+    if (h->g_exact) return FRP_OK;
+    DevBuf fresh;
+    if (h->g_rows > 0) {          // rows that exist already: the unit fp16 rows widened (their exact values are gone)
+        const size_t cap_rows = std::max<size_t>(h->gallery.cap / ((size_t)FRP_EMB_DIM * 2), (size_t)h->g_rows);
+        FRPCHK(ensure(h, fresh, cap_rows * FRP_EMB_DIM * 8));
+        hipError_t e = launch_gallery_widen((const _Float16*)h->gallery.p, (double*)fresh.p, h->g_rows, FRP_EMB_DIM, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { release(fresh); return fail(h, FRP_ERR_HIP, std::string("gallery_widen: ") + hipGetErrorString(e)); }
+    }
+    release(h->gx);
+    h->gx = fresh;
+    h->g_exact = true;
+    return FRP_OK;
+}
+
+int frp_gallery_distances(frp_handle* h, const double* q, int32_t M, double* dist, int64_t n_cols) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->g_exact) return fail(h, FRP_ERR_INVALID, "exact rows are not enabled (frp_gallery_exact)");
+    if (!q || !dist || M <= 0 || M > 65536) return fail(h, FRP_ERR_INVALID, "bad distance arguments");
+    if (n_cols != h->g_rows) return fail(h, FRP_ERR_INVALID, "gallery_distances: output sized for another gallery size");
+    if (h->g_rows == 0) return FRP_OK;
+    FRPCHK(ensure(h, h->gx_q, (size_t)M * FRP_EMB_DIM * 8));
+    FRPCHK(ensure(h, h->gx_out, (size_t)M * h->g_rows * 8));
+    HIPCHK(h, hipMemcpyAsync(h->gx_q.p, q, (size_t)M * FRP_EMB_DIM * 8, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_gallery_distances((const double*)h->gx.p, h->g_rows, (const double*)h->gx_q.p, M, (double*)h->gx_out.p, h->stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("gallery_distances: ") + hipGetErrorString(e));
+    HIPCHK(h, hipMemcpyAsync(dist, h->gx_out.p, (size_t)M * h->g_rows * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+int frp_gallery_get_exact(frp_handle* h, double* out, int64_t first_row, int64_t n_rows) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->g_exact) return fail(h, FRP_ERR_INVALID, "exact rows are not enabled (frp_gallery_exact)");
+    if (!out || first_row < 0 || n_rows < 0 || first_row + n_rows > h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery range");
+    if (n_rows == 0) return FRP_OK;
+    HIPCHK(h, hipMemcpyAsync(out, (double*)h->gx.p + first_row * FRP_EMB_DIM, (size_t)n_rows * FRP_EMB_DIM * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return FRP_OK;
 }

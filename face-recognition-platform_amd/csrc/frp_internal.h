@@ -180,6 +180,10 @@ __host__ __device__ inline int conv_pick_ksplit(int M, int Cout, int Ktot, int f
 }
 // gallery upload: fp32 rows -> unit fp16 rows
 hipError_t launch_gallery_normalize(const float* in, _Float16* out, long N, int D, hipStream_t stream);
+// exact compat rows (frp.h: frp_gallery_exact): unit fp16 rows widened to float64; Euclidean distances of M float64 queries to the
+// N float64 rows, out[m * N + row] (face_recognition.face_distance, face_service.py:410,465,599)
+hipError_t launch_gallery_widen(const _Float16* in, double* out, long N, int D, hipStream_t stream);
+hipError_t launch_gallery_distances(const double* rows, long N, const double* q, int M, double* out, hipStream_t stream);
 
 #ifdef FRP_LAB
 hipError_t launch_mfma_peak(const _Float16* src, float* dst, int blocks, int iters, hipStream_t stream);

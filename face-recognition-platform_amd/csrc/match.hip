@@ -384,4 +384,63 @@ hipError_t launch_topk_rows(const float* scores, int M, long N, int k, int32_t* 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Exact rows of the REST-style compat path (frp.h: frp_gallery_exact / frp_gallery_distances).  HBM-bound: 4 KB per row and
+// pass (N x 512 float64), the arithmetic - 512 float64 subtract + FMA per row and query - is a few per cent of the fp64 rate.
+__global__ void gallery_widen_kernel(const _Float16* in, double* out, long n_elems) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n_elems) return;
+    const half8 v = *reinterpret_cast<const half8*>(in + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[i + e] = (double)(float)v[e];
+}
+hipError_t launch_gallery_widen(const _Float16* in, double* out, long N, int D, hipStream_t stream) {
+    const long n = N * D;
+    if (n <= 0) return hipSuccess;
+    if (D % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_widen_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}
+
+// One wave per gallery row (a workgroup of four waves walks rows blockIdx * 4 + wave, + 4 gridDim, ...): lane l holds elements
+// l, l + 64, ... of the row (8 coalesced 512-byte loads) and, per query of the chunk in LDS, sums its eight squared differences
+// in that order; the 64 partial sums are combined by a butterfly (xor 32, 16, ... 1): a fixed order, so a distance depends on the
+// row and the query only - not on N, M or the launch geometry.  sqrt is the correctly rounded one.
+#define GD_QCHUNK 8
+__global__ __launch_bounds__(256) void gallery_distances_kernel(const double* __restrict__ rows, long N, const double* __restrict__ q, int M,
+                                                                 double* __restrict__ out) {
+    __shared__ double qs[GD_QCHUNK][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m0 = 0; m0 < M; m0 += GD_QCHUNK) {
+        const int mc = M - m0 < GD_QCHUNK ? M - m0 : GD_QCHUNK;
+        __syncthreads();
+        for (int i = threadIdx.x; i < mc * 512; i += 256) qs[i >> 9][i & 511] = q[(long)m0 * 512 + i];
+        __syncthreads();
+        for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+            double g[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = rows[r * 512 + lane + 64 * i];
+            for (int m = 0; m < mc; ++m) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double d = g[i] - qs[m][lane + 64 * i];
+                    acc = __builtin_fma(d, d, acc);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (lane == 0) out[(long)(m0 + m) * N + r] = __builtin_sqrt(acc);
+            }
+        }
+    }
+}
+hipError_t launch_gallery_distances(const double* rows, long N, const double* q, int M, double* out, hipStream_t stream) {
+    if (N <= 0 || M <= 0) return hipSuccess;
+    long blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gallery_distances_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, N, q, M, out);
+    return hipGetLastError();
+}
+
 }  // namespace frp

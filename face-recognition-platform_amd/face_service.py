@@ -107,6 +107,15 @@ class FaceService:
         self._weights_blob = weights_blob
         self._storage = storage or NullStorage()
         self.ENCODINGS = Gallery(self._eng)
+        # REST-style compat calls (compare_faces, find_k_nearest, batch_compare_faces, the duplicate scan, cluster_faces) score
+        # against float64 copies of the rows AS ENROLLED (frp_gallery_exact / frp_gallery_distances): the reference's own
+        # arithmetic (face_service.py:409-410), distances equal to 1e-6 - also for an exact copy (0.0), for d == tolerance, for
+        # rows that are not unit vectors and for 128-d rows.  FRP_EXACT_COMPAT=0: cosines of the unit fp16 rows instead
+        # (4 KB per identity less device memory; distances good to ~2e-3, 0.03 near 0).
+        self._exact = os.getenv("FRP_EXACT_COMPAT", "1") != "0"
+        if engine is not None and self._exact and hasattr(engine, "gallery_exact"):
+            engine.gallery_exact(True)
+            self.ENCODINGS.exact = True
         # process_stream keeps two batches in flight on the GPU (lanes.py): a second handle with its own copy of the
         # gallery, fed by every update from the start (Gallery.add_mirror).  Created on first use, or injected (tests).
         self._engine2 = second_engine
@@ -142,6 +151,9 @@ class FaceService:
                             blob = weights.synthetic_blob()
                     eng.load_weights(blob)
                     self._blob_loaded = blob
+                    if self._exact:
+                        eng.gallery_exact(True)
+                        self.ENCODINGS.exact = True
                     self._engine = eng
         return self._engine
 
@@ -351,6 +363,9 @@ class FaceService:
             targets = G.names() if names is None else [t for t in names if t in G]
             if not targets:
                 return [], np.zeros((0,))
+            if G.exact:            # float64 Euclidean distances to the rows as enrolled (face_recognition.face_distance, :410)
+                d = self._eng().gallery_distances(np.asarray(encoding, dtype=np.float64).reshape(1, -1))[0]
+                return targets, d[G.rows_of(targets)]
             q = np.asarray(encoding, dtype=np.float32).reshape(1, -1)
             cos = self._eng().match_scores(q)[0]
             return targets, cos_to_distance(cos[G.rows_of(targets)])
@@ -450,8 +465,12 @@ class FaceService:
                 targets = G.names() if target_names is None else [t for t in target_names if t in G]
                 if not targets:
                     return [[] for _ in test_encodings]
-                Q = np.stack([np.asarray(q, dtype=np.float32).reshape(-1) for q in test_encodings])
-                D = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(targets)])
+                if G.exact:
+                    Q = np.stack([np.asarray(q, dtype=np.float64).reshape(-1) for q in test_encodings])
+                    D = self._eng().gallery_distances(Q)[:, G.rows_of(targets)]
+                else:
+                    Q = np.stack([np.asarray(q, dtype=np.float32).reshape(-1) for q in test_encodings])
+                    D = cos_to_distance(self._eng().match_scores(Q)[:, G.rows_of(targets)])
         except Exception as e:
             logger.exception("Error in batch comparison: %s", e)
             return [[] for _ in test_encodings]
@@ -477,7 +496,7 @@ class FaceService:
                 return {"cluster_0": G.names()}
             names = G.names()
             rows = G.rows_of(names)
-            emb = self._eng().gallery_get().astype(np.float32)[rows]
+            emb = self._eng().gallery_get_exact()[rows] if G.exact else self._eng().gallery_get().astype(np.float32)[rows]
             clusters: Dict[str, List[str]] = {}
             assigned = np.zeros(len(names), dtype=bool)
             cid = 0
@@ -492,7 +511,8 @@ class FaceService:
                 if i not in tile_rows:                 # next tile: the first CLUSTER_TILE unassigned names from i on
                     cand = [j for j in range(i, len(names)) if not assigned[j]][:CLUSTER_TILE]
                     tile_rows = {j: t for t, j in enumerate(cand)}
-                    tile = cos_to_distance(self._eng().match_scores(emb[cand])[:, rows])
+                    tile = (self._eng().gallery_distances(emb[cand])[:, rows] if G.exact
+                            else cos_to_distance(self._eng().match_scores(emb[cand])[:, rows]))
                 d = tile[tile_rows[i]]
                 take = (~assigned) & (d <= distance_threshold)
                 take[i] = True
@@ -511,7 +531,7 @@ class FaceService:
         k = min(int(k), n)
         if k < 1:
             return []
-        if k > native.MAX_TOPK:                      # beyond the device limit: full score row + host selection
+        if self.ENCODINGS.exact or k > native.MAX_TOPK:   # exact rows (or k beyond the device limit): full distance row + host selection
             targets, distances = self._distances(test_encoding)
             idx = np.argsort(distances, kind="stable")[:k]
             pairs = [(targets[int(i)], float(distances[int(i)])) for i in idx]

@@ -94,6 +94,8 @@ class Gallery(Mapping):
         self._rows: Dict[str, int] = {}    # insertion-ordered: name -> device row
         self._names: List[Optional[str]] = []   # device row -> name
         self._lock = _RWLock()
+        self.exact = False                 # the first engine keeps float64 rows as enrolled (enable_exact)
+        self.dim = 0                       # width of the rows as enrolled (the reference's encodings are 128-d; device rows are padded to 512)
 
     def add_mirror(self, engine) -> None:
         """A second engine that receives every update from now on (two batches in flight on one GPU: each lane matches
@@ -125,9 +127,26 @@ class Gallery(Mapping):
         return name in self._rows
 
     def __getitem__(self, name: str) -> list:
+        """the stored row: as enrolled (float64) when the engine keeps exact rows (FaceService's default), else the unit fp16 row"""
         with self._lock:
             row = self._rows[name]
-            return self._eng().gallery_get(row, 1)[0].astype(np.float64).tolist()
+            eng = self._eng()
+            if self.exact and hasattr(eng, "gallery_get_exact"):
+                v = eng.gallery_get_exact(row, 1)[0]
+                return v[: self.dim].tolist() if self.dim else v.tolist()
+            return eng.gallery_get(row, 1)[0].astype(np.float64).tolist()
+
+    def enable_exact(self) -> bool:
+        """Switch the first engine to exact rows (frp_gallery_exact): float64 copies of the rows as enrolled, the operands of the
+        REST-style compat path (compare_faces / find_k_nearest / batch_compare_faces / duplicate scan / cluster_faces; the streaming
+        lanes keep matching on the unit fp16 rows, and their mirrors hold no exact copy).  -> whether the engine supports it"""
+        with self._lock:
+            eng = self._eng()
+            if not hasattr(eng, "gallery_exact"):
+                return False
+            eng.gallery_exact(True)
+            self.exact = True
+            return True
 
     def locked(self):
         """The lock every update takes.  A reader that resolves device row indices to names (match ->
@@ -152,7 +171,10 @@ class Gallery(Mapping):
     def put(self, name: str, emb: np.ndarray) -> bool:
         """insert or overwrite; returns True if the name already existed."""
         with self._lock:
-            e = np.asarray(emb, dtype=np.float32).reshape(-1)
+            e = np.asarray(emb)
+            e = e.astype(np.float64 if e.dtype == np.float64 else np.float32, copy=False).reshape(-1)   # (float64 stays: exact rows)
+            if not self._names:
+                self.dim = int(e.shape[0])
             engines = self._engines()
             if name in self._rows:
                 row = self._rows[name]
@@ -223,6 +245,7 @@ class Gallery(Mapping):
                 eng.gallery_set(np.asarray(emb))
             self._rows = {n: i for i, n in enumerate(names)}
             self._names = list(names)
+            self.dim = int(np.asarray(emb).shape[1]) if len(names) else 0
 
     def adopt_device(self, names: List[str]):
         """name table for a matrix that was installed with frp_gallery_set_device."""

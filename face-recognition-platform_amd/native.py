@@ -30,7 +30,7 @@ F32, F16, F64 = 0, 1, 2
 ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
-    "frp_gallery_size", "frp_gallery_get",
+    "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
     "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
@@ -108,6 +108,9 @@ def load_library() -> C.CDLL:
     lib.frp_gallery_size.argtypes = [vp]
     lib.frp_gallery_size.restype = i64
     lib.frp_gallery_get.argtypes = [vp, vp, i64, i64]
+    lib.frp_gallery_exact.argtypes = [vp, i32]
+    lib.frp_gallery_distances.argtypes = [vp, vp, i32, vp, i64]
+    lib.frp_gallery_get_exact.argtypes = [vp, vp, i64, i64]
     lib.frp_process_frames.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, f32, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.frp_upload_frames.argtypes = [vp, vp, i32, i32, i32, i64]
     lib.frp_process_resident.argtypes = [vp, i32, f32, f32, u32]
@@ -201,6 +204,8 @@ class Engine:
         dt = {np.dtype(np.float32): F32, np.dtype(np.float16): F16, np.dtype(np.float64): F64}.get(emb.dtype)
         if dt is None:
             emb, dt = emb.astype(np.float32), F32
+        if emb.ndim == 2 and emb.shape[1] < EMB_DIM:          # narrower rows (128-d): zero-padded
+            emb = np.ascontiguousarray(np.concatenate([emb, np.zeros((emb.shape[0], EMB_DIM - emb.shape[1]), emb.dtype)], axis=1))
         self._chk(self._lib.frp_gallery_set(self._h, _ptr(emb), emb.shape[0], emb.shape[1], dt))
 
     def gallery_set_device(self, dev_ptr: int, n: int):
@@ -219,9 +224,51 @@ class Engine:
         """device address of the current snapshot (0 when empty); valid until the next gallery update"""
         return int(self._lib.frp_gallery_device_ptr(self._h) or 0)
 
+    @staticmethod
+    def _row512(emb: np.ndarray) -> Tuple[np.ndarray, int]:
+        """one embedding as the library takes it: 512 float32 or - a float64 input stays float64, so the exact compat rows
+        (gallery_exact) hold it bit for bit - float64 values; narrower rows (the reference's 128-d dlib encodings) are
+        zero-padded, which changes neither a cosine nor a Euclidean distance"""
+        e = np.asarray(emb)
+        dt, code = (np.float64, F64) if e.dtype == np.float64 else (np.float32, F32)
+        e = np.ascontiguousarray(e, dtype=dt).reshape(-1)
+        if e.shape[0] < EMB_DIM:
+            e = np.concatenate([e, np.zeros(EMB_DIM - e.shape[0], dt)])
+        return e, code
+
     def gallery_update_row(self, row: int, emb: np.ndarray):
-        e = np.ascontiguousarray(emb, dtype=np.float32).reshape(-1)
-        self._chk(self._lib.frp_gallery_update_row(self._h, row, _ptr(e), e.shape[0], F32))
+        e, code = self._row512(emb)
+        self._chk(self._lib.frp_gallery_update_row(self._h, row, _ptr(e), e.shape[0], code))
+
+    def gallery_exact(self, on: bool = True):
+        """keep every row also as float64, as enrolled (frp.h: frp_gallery_exact): the rows behind gallery_distances"""
+        self._chk(self._lib.frp_gallery_exact(self._h, 1 if on else 0))
+
+    def gallery_distances(self, q: np.ndarray) -> np.ndarray:
+        """Euclidean distances [M, N] (float64) of M queries to the exact rows: face_recognition.face_distance on the device"""
+        q = np.asarray(q, dtype=np.float64)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        if q.shape[1] < EMB_DIM:
+            q = np.concatenate([q, np.zeros((q.shape[0], EMB_DIM - q.shape[1]))], axis=1)
+        q = np.ascontiguousarray(q)
+        if q.shape[1] != EMB_DIM:
+            raise ValueError("queries must have at most 512 values")
+        for _ in range(8):
+            n = self.gallery_size()
+            out = np.empty((q.shape[0], n), np.float64)
+            rc = self._lib.frp_gallery_distances(self._h, _ptr(q), q.shape[0], _ptr(out), n)
+            if rc == 0:
+                return out
+            if self.gallery_size() == n:
+                break
+        self._chk(rc)
+        return out
+
+    def gallery_get_exact(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = self.gallery_size() - first if n is None else n
+        out = np.empty((n, EMB_DIM), dtype=np.float64)
+        self._chk(self._lib.frp_gallery_get_exact(self._h, _ptr(out), first, n))
+        return out
 
     def gallery_remove_row(self, row: int):
         self._chk(self._lib.frp_gallery_remove_row(self._h, row))

@@ -122,6 +122,24 @@ int64_t frp_gallery_size(const frp_handle* h);
 /* copy the normalised fp16 gallery back to the host (n_rows x 512 uint16) */
 int frp_gallery_get(frp_handle* h, void* out_f16, int64_t first_row, int64_t n_rows);
 
+/* ---- exact rows for the REST-style compat path ---------------------------------------
+ * replaces: the float64 arithmetic of face_recognition.face_distance on the rows AS ENROLLED
+ * (np.linalg.norm(np.array([ENCODINGS[t] ...]) - q, axis=1): face_service.py:409-410,461-465,595-599, the 1-vs-1 calls of the
+ * duplicate scan :357 and of cluster_faces :576).  The streaming loop matches on the unit fp16 rows (frp_match, the fused top-1 of
+ * frp_process_*); compare_faces / find_k_nearest / batch_compare_faces / the duplicate scan report distances that must agree with
+ * the reference's to 1e-6 - also for an exact copy (d = 0, where sqrt(2 - 2 cos) of fp16 rows reads 0.01-0.03), for d == tolerance,
+ * for rows that are not unit vectors and for 128-d rows.
+ * frp_gallery_exact(h, 1): from now on every row is ALSO kept as float64 [N x 512], exactly as handed to frp_gallery_set /
+ * frp_gallery_update_row (dtype FRP_F64: bit for bit; FRP_F32 / FRP_F16: widened; not normalised; rows narrower than 512 are
+ * zero-padded by the caller), 4 KB per row; rows that exist when it is switched on, and rows installed from device fp16 data
+ * (frp_gallery_set_device, frp_gallery_commit), are the unit fp16 rows widened.  frp_gallery_exact(h, 0) frees the copy.
+ * frp_gallery_distances: dist[m * n_cols + row] = ||row - q_m||_2 in float64 (differences, squares and sums in float64, one
+ * correctly rounded sqrt; the summation order is fixed, so a result does not depend on N or M) for M queries of 512 doubles;
+ * n_cols as in frp_match_scores.  frp_gallery_get_exact copies rows back (n_rows x 512 doubles). */
+int frp_gallery_exact(frp_handle* h, int32_t on);
+int frp_gallery_distances(frp_handle* h, const double* q, int32_t M, double* dist, int64_t n_cols);
+int frp_gallery_get_exact(frp_handle* h, double* out, int64_t first_row, int64_t n_rows);
+
 /* ---- the hot path -----------------------------------------------------------------
  * replaces, per frame: cv2.cvtColor(BGR2RGB) (camera.py:225), face_recognition.face_locations
  * (camera.py:232, face_service.py:156), the max_faces cap (camera.py:233-235),
