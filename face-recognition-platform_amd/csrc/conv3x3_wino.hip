@@ -916,19 +916,25 @@ bool conv3x3_wino_eligible(const ConvParams& p) {
     if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
     if (p.Ho != p.H || p.Wo != p.W) return false;
     if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return false;
-
-    if (!conv3x3_wino_shape_ok(p.W, p.Cin, p.KS, p.stride)) return false;
+    bool shape = conv3x3_wino_shape_ok(p.W, p.Cin, p.KS, p.stride);
+#ifdef FRP_LAB    // the row-patch form for wide maps (measured slower than the direct kernel, not shipped): only when asked for by
+    shape = shape || ((p.dbg & 64) && conv3x3_wino_lab_shape_ok(p.W, p.Cin, p.KS, p.stride));      // dbg bit 64 (conv_bench / conv2d)
+#endif
+    if (!shape) return false;
     const long reach = ((long)p.M + 2L * p.W + 600) * p.Cin * 2;       // signed 32-bit patch offsets
     return reach < 0x7fffffffL;
 }
 
+// The same answer in the shipped and in the lab build: frp_load_weights builds Winograd images - and run_net routes layers to
+// this kernel - for exactly the same layers in both, so engine-level runs on libfrp_lab.so time and compute what libfrp.so does.
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride) {
-#ifdef FRP_LAB
-    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2;      // (wide maps: the row-patch form, lab build)
-#else
     return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2 && wino_super_patch(W);
-#endif
 }
+#ifdef FRP_LAB
+bool conv3x3_wino_lab_shape_ok(int W, int Cin, int ksize, int stride) {      // + wide maps (row-patch form, dbg bit 64)
+    return ksize == 3 && stride == 1 && !(Cin & 63) && !(W & 1) && W >= 2;
+}
+#endif
 
 // bytes of the transformed weight image of a layer (the `w` operand of the Winograd kernel)
 size_t conv3x3_wino_image_bytes(int Cin, int Cout) {
@@ -1019,7 +1025,7 @@ hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     }
 #endif
 #ifdef FRP_LAB
-    if (!wino_super_patch(p.W) || (p.dbg & 64)) return launch_wino_cfg<8, 0, true>(p, stream);     // wide maps (dbg bit 64: force, A/B)
+    if (p.dbg & 64) return launch_wino_cfg<8, 0, true>(p, stream);     // row-patch form (first generation; wide maps, or forced for an A/B)
 #endif
     if (!wino_super_patch(p.W)) return hipErrorInvalidValue;
     return launch_wino_cfg<8>(p, stream);

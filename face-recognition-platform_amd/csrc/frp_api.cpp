@@ -691,16 +691,24 @@ int run_match(frp_handle* h, int n, float* all_scores_dev, const int32_t* n_dev 
 
 // align + embed + match for the faces listed in h->kps / h->counts / h->face_slot (device), always from
 // the full-resolution resident frames.  n_known >= 0: face count known on the host.
+int resolve_count(frp_handle* h);
 int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
     const int B = h->rB;
     int n;
+    // a device-count pass that nobody fetched or synchronised yet (two process calls queued back to back): its count and its
+    // counter corrections live in single slots (h_nfaces, pend_*) this pass is about to reuse - settle it first
+    if (h->last_nfaces < 0) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        FRPCHK(resolve_count(h));
+    }
     // Threshold mode (the reference's loop, routes/camera.py:232-259): how many faces the detector kept is known on the
     // device only.  It STAYS there: align, the embedder's kernels, the l2norm and the matcher are launched for the capacity
     // B x K and read the count from device memory (grids sized for the capacity; workgroups beyond the real tiles leave at
     // once), so the pipeline has no host round trip.  The host learns the count with the results (frp_fetch_results).
     // FRP_HOST_COUNT=1 keeps the former path (copy the count, wait, launch for exactly n) for A/B runs - both give the
     // same bits.  More than FRP_MATCH_TOP1_MAX slots: the per-tile matcher has no device-count form, former path.
-    const bool dev_count = n_known < 0 && round_up(B * K, 32) <= FRP_MATCH_TOP1_MAX && !getenv("FRP_HOST_COUNT");
+    // (FRP_MATCH_V1=1 pins the per-tile matcher for A/B runs: it has no device-count form either)
+    const bool dev_count = n_known < 0 && round_up(B * K, 32) <= FRP_MATCH_TOP1_MAX && !getenv("FRP_HOST_COUNT") && !getenv("FRP_MATCH_V1");
     const int32_t* n_dev = nullptr;
     if (n_known >= 0) {
         n = n_known;
@@ -757,16 +765,20 @@ int run_faces(frp_handle* h, int K, int n_known, uint32_t flags) {
 }
 
 // the face count of a device-count pass, once the stream has been waited for (h_nfaces was copied behind the pass)
-void resolve_count(frp_handle* h) {
-    if (h->last_nfaces >= 0) return;
+int resolve_count(frp_handle* h) {
+    if (h->last_nfaces >= 0) return FRP_OK;
     int n = *h->h_nfaces;
-    if (n < 0 || n > h->last_cap) n = 0;
+    const bool corrupt = n < 0 || n > h->last_cap;     // (the host-count path fails the same way: "corrupt face count")
+    if (corrupt) n = 0;
     h->last_nfaces = n;
     h->ctr.faces += n;
     if (h->pend_cap > 0) {
         h->ctr.emb_conv_flops += h->pend_flops * n / h->pend_cap - h->pend_flops;
         h->ctr.f8_conv_flops += h->pend_f8flops * n / h->pend_cap - h->pend_f8flops;
     }
+    h->pend_cap = 0;
+    h->pend_flops = h->pend_f8flops = 0.0;
+    return corrupt ? fail(h, FRP_ERR_HIP, "corrupt face count") : FRP_OK;
 }
 
 int run_pipeline(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t flags) {
@@ -847,7 +859,7 @@ int fetch_results(frp_handle* h, float* boxes, float* kps, float* scores, int32_
     if (B <= 0) return fail(h, FRP_ERR_INVALID, "nothing to fetch");
     if (h->last_nfaces < 0) {                  // device-count pass: one short wait for the count, then copy exactly n rows
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        resolve_count(h);
+        FRPCHK(resolve_count(h));
     }
     const int n = h->last_nfaces;
     const size_t s = (size_t)B * K;
@@ -1185,7 +1197,7 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
 int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_t dtype) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
+    if (h->g_reserved.p) return fail(h, FRP_ERR_INVALID, "a gallery reservation is pending: commit or cancel it first (frp_gallery_commit / frp_gallery_cancel)");
     if (n < 0 || (n > 0 && !emb) || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512]");
     DevBuf fresh, fresh_x;   // new snapshot(s), swapped in when complete
     if (n > 0) {
@@ -1212,7 +1224,7 @@ int frp_gallery_set(frp_handle* h, const void* emb, int64_t n, int32_t d, int32_
 int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_t d) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
+    if (h->g_reserved.p) return fail(h, FRP_ERR_INVALID, "a gallery reservation is pending: commit or cancel it first (frp_gallery_commit / frp_gallery_cancel)");
     if (n <= 0 || !dev_f16 || d != FRP_EMB_DIM) return fail(h, FRP_ERR_INVALID, "gallery must be [n x 512] fp16 on the device");
     DevBuf fresh;
     FRPCHK(ensure(h, fresh, (size_t)n * d * 2));
@@ -1236,6 +1248,16 @@ int frp_gallery_reserve(frp_handle* h, int64_t capacity_rows, void** dev_f16) {
     release(h->g_reserved);
     FRPCHK(ensure(h, h->g_reserved, (size_t)capacity_rows * FRP_EMB_DIM * 2));
     *dev_f16 = h->g_reserved.p;
+    return FRP_OK;
+}
+
+int frp_gallery_cancel(frp_handle* h) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (h->g_reserved.p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        release(h->g_reserved);
+    }
     return FRP_OK;
 }
 
@@ -1265,7 +1287,7 @@ const void* frp_gallery_device_ptr(frp_handle* h) {
 int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t d, int32_t dtype) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
+    if (h->g_reserved.p) return fail(h, FRP_ERR_INVALID, "a gallery reservation is pending: commit or cancel it first (frp_gallery_commit / frp_gallery_cancel)");
     if (!emb || d != FRP_EMB_DIM || row < 0 || row > h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
     std::vector<float> f;
     FRPCHK(to_f32(h, emb, (size_t)d, dtype, f));
@@ -1303,7 +1325,7 @@ int frp_gallery_update_row(frp_handle* h, int64_t row, const void* emb, int32_t 
 int frp_gallery_remove_row(frp_handle* h, int64_t row) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
-    release(h->g_reserved);          // any other gallery call discards a pending reservation (frp.h)
+    if (h->g_reserved.p) return fail(h, FRP_ERR_INVALID, "a gallery reservation is pending: commit or cancel it first (frp_gallery_commit / frp_gallery_cancel)");
     if (row < 0 || row >= h->g_rows) return fail(h, FRP_ERR_INVALID, "bad gallery row");
     const int64_t last = h->g_rows - 1;
     if (row != last) {
@@ -1468,7 +1490,7 @@ int frp_synchronize(frp_handle* h) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h, false);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    resolve_count(h);
+    FRPCHK(resolve_count(h));
     settle_events(h, true);
     return FRP_OK;
 }
@@ -1809,7 +1831,11 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     const bool want_wino = (flags & 0x10000) != 0;
     std::vector<uint16_t> wimg;
     if (want_wino) {
-        if (!conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2)))
+        bool shape_ok = conv3x3_wino_shape_ok(W, Cin, ksize, stride);
+#ifdef FRP_LAB
+        shape_ok = shape_ok || ((((flags >> 8) & 0xff) & 64) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
+#endif
+        if (!shape_ok || (flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2)))
             return fail(h, FRP_ERR_INVALID, "shape not covered by the Winograd kernel");
         wimg.resize(conv3x3_wino_image_bytes(Cin, Cout) / 2);
         build_wino_image((const uint16_t*)w, Cin, Cout, wimg.data());
@@ -1942,7 +1968,11 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         p.dbg = (flags >> 8) & 0xff;
         p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
-        if ((flags & 0x10000) && conv3x3_wino_shape_ok(W, Cin, ksize, stride)) {     // Winograd kernel: a random weight image (timing only)
+        bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride);
+#ifdef FRP_LAB
+        wino_shape = wino_shape || ((p.dbg & 64) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
+#endif
+        if ((flags & 0x10000) && wino_shape) {     // Winograd kernel: a random weight image (timing only)
             const size_t ib = conv3x3_wino_image_bytes(Cin, Cout);
             if (ensure(h, dwino, ib) == FRP_OK) {
                 e = launch_fill_random_f16((_Float16*)dwino.p, (long)(ib / 2), 5u, 1.0f / sqrtf((float)(9 * Cin)), h->stream);

@@ -69,6 +69,9 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // st
 // the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
 bool conv3x3_wino_eligible(const ConvParams& p);
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride);
+#ifdef FRP_LAB
+bool conv3x3_wino_lab_shape_ok(int W, int Cin, int ksize, int stride);   // + the maps only the lab's row-patch form covers (dbg bit 64)
+#endif
 size_t conv3x3_wino_image_bytes(int Cin, int Cout);
 hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream);
 

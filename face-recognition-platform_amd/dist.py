@@ -78,10 +78,16 @@ def gallery_checksum(mat) -> int:
     return int(((v * w).sum() % ((1 << 61) - 1)).item())
 
 
-def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int, int], np.ndarray], local_rank: int):
+def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int, int], np.ndarray], local_rank: int, gallery=None):
     """Rank r builds rows shard_range(n_total, r, R) on the host, uploads them as unit fp16 and all-gathers over RCCL
     STRAIGHT INTO the snapshot the first engine reserved (frp_gallery_reserve / frp_gallery_commit): the matrix exists
-    once per handle, not three more times in torch tensors.  Further lanes of this GPU copy theirs from the first."""
+    once per handle, not three more times in torch tensors.  Further lanes of this GPU copy theirs from the first.
+    `gallery`: the gallery.Gallery over these engines, if there is one - its exclusive lock is held from reserve to commit, so
+    an enrolment on another thread waits instead of being refused by the library (which rejects every other gallery update
+    while a reservation is pending: RCCL is writing into it)."""
+    if gallery is not None:
+        with gallery.locked():
+            return allgather_gallery_into_engine(engine, n_total, make_rows, local_rank)
     import torch
     import torch.distributed as dist
     engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
@@ -91,9 +97,13 @@ def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int
     block = (n_total + world - 1) // world
     dev = torch.device("cuda", local_rank)
     ptr = engines[0].gallery_reserve(world * block)
-    out = torch.as_tensor(_DevicePtr(ptr, world * block, 512), device=dev)
-    allgather_gallery(shard, n_total, device=dev, out=out)
-    torch.cuda.synchronize()
+    try:
+        out = torch.as_tensor(_DevicePtr(ptr, world * block, 512), device=dev)
+        allgather_gallery(shard, n_total, device=dev, out=out)
+        torch.cuda.synchronize()
+    except BaseException:
+        engines[0].gallery_cancel()
+        raise
     engines[0].gallery_commit(n_total)
     for e in engines[1:]:                                    # every lane of this GPU matches against its own copy
         e.gallery_set_device(engines[0].gallery_device_ptr(), n_total)

@@ -29,7 +29,7 @@ F32, F16, F64 = 0, 1, 2
 
 ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
-    "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
+    "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_cancel", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
     "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     lib.frp_gallery_set_device.argtypes = [vp, vp, i64, i32]
     lib.frp_gallery_reserve.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
     lib.frp_gallery_commit.argtypes = [vp, i64]
+    lib.frp_gallery_cancel.argtypes = [vp]
     lib.frp_gallery_device_ptr.argtypes = [vp]
     lib.frp_gallery_device_ptr.restype = vp
     lib.frp_gallery_update_row.argtypes = [vp, i64, vp, i32, i32]
@@ -219,6 +220,10 @@ class Engine:
 
     def gallery_commit(self, n_rows: int):
         self._chk(self._lib.frp_gallery_commit(self._h, n_rows))
+
+    def gallery_cancel(self):
+        """discard a pending reservation (other gallery updates are refused while one is pending)"""
+        self._chk(self._lib.frp_gallery_cancel(self._h))
 
     def gallery_device_ptr(self) -> int:
         """device address of the current snapshot (0 when empty); valid until the next gallery update"""

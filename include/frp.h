@@ -109,10 +109,13 @@ int frp_gallery_set_device(frp_handle* h, const void* dev_f16, int64_t n, int32_
 /* Zero-copy import of a matrix produced ON this GPU (the RCCL all-gather of the watch-list shards):
  * frp_gallery_reserve allocates a fresh, not yet visible snapshot of `capacity_rows` x 512 fp16 and returns its device
  * address; the caller (a collective, a kernel) fills rows [0, n) with UNIT fp16 rows and finishes its stream work;
- * frp_gallery_commit(n) makes it the gallery (n <= capacity; the old snapshot is released).  A second reserve, or any
- * other gallery call in between, discards the reservation. */
+ * frp_gallery_commit(n) makes it the gallery (n <= capacity; the old snapshot is released).  While a reservation is pending -
+ * someone else (RCCL) may be writing into it - the other gallery updates (set, set_device, update_row, remove_row) FAIL with
+ * FRP_ERR_INVALID and change nothing; frp_gallery_cancel discards the reservation (no-op without one); a second reserve
+ * replaces the first. */
 int frp_gallery_reserve(frp_handle* h, int64_t capacity_rows, void** dev_f16);
 int frp_gallery_commit(frp_handle* h, int64_t n_rows);
+int frp_gallery_cancel(frp_handle* h);
 /* device address of the current snapshot (rows [0, frp_gallery_size)), valid until the next gallery update on this handle:
  * the source from which a second handle on the same GPU copies its own snapshot (frp_gallery_set_device) */
 const void* frp_gallery_device_ptr(frp_handle* h);

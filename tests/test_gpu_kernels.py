@@ -755,8 +755,8 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
 def test_gallery_reserve_commit_zero_copy_import(engine):
     """frp_gallery_reserve / _commit / _device_ptr (the RCCL all-gather lands in the snapshot the engine reserved,
     dist.allgather_gallery_into_engine): rows written into the reserved buffer by another producer on the GPU (torch here)
-    become the gallery at commit, a second handle copies its snapshot from the first one's device pointer, and a
-    reservation does not survive another gallery call"""
+    become the gallery at commit, a second handle copies its snapshot from the first one's device pointer; while a
+    reservation is pending the other gallery updates are refused and change nothing; cancel discards it"""
     from frp_amd import dist as fdist, native
     from frp_amd.native import FrpError
     rng = np.random.default_rng(15)
@@ -776,10 +776,21 @@ def test_gallery_reserve_commit_zero_copy_import(engine):
     e2.gallery_set_device(engine.gallery_device_ptr(), 777)
     assert np.array_equal(e2.gallery_get(0, 777), rows)
     e2.close()
+    ptr2 = engine.gallery_reserve(64)
+    for bad in (lambda: engine.gallery_update_row(0, q[0]), lambda: engine.gallery_remove_row(0),
+                lambda: engine.gallery_set(q), lambda: engine.gallery_set_device(engine.gallery_device_ptr(), 5)):
+        with pytest.raises(FrpError):                        # someone (RCCL) may be writing into the reservation: updates wait
+            bad()
+    assert engine.gallery_size() == 777 and np.array_equal(engine.gallery_get(0, 777), rows)      # nothing changed
+    t2 = torch.as_tensor(fdist._DevicePtr(ptr2, 64, 512), device=torch.device("cuda", 0))
+    t2[:10].copy_(torch.from_numpy(rows[100:110]))
+    torch.cuda.synchronize()
+    engine.gallery_commit(10)                                # ... and the reservation survived them
+    assert engine.gallery_size() == 10 and np.array_equal(engine.gallery_get(0, 10), rows[100:110])
     engine.gallery_reserve(64)
-    engine.gallery_update_row(0, q[0])                       # any other gallery call discards the reservation
+    engine.gallery_cancel()
+    engine.gallery_cancel()                                  # (no-op without a reservation)
     with pytest.raises(FrpError):
-        engine.gallery_commit(10)
-    with pytest.raises(FrpError):
-        engine.gallery_commit(5)                             # ... and there is nothing to commit without one
+        engine.gallery_commit(5)                             # nothing to commit
+    engine.gallery_update_row(0, q[0])                       # updates work again
     engine.gallery_set(np.zeros((0, 512), np.float32))
