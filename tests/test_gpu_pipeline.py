@@ -864,3 +864,54 @@ def test_full_size_detector_vs_oracle_one_frame(engine):
         err = np.abs(g[0, ..., :30].astype(np.float32) - r[0]).max()
         assert err < 2e-2 * scale, (err, scale)
         assert np.array_equal(g[0], g[1]) and np.array_equal(g[0], g[2])     # position in the batch does not matter
+
+
+EMB_ONNX_LAYOUTS = [dict(named=True), dict(named=False), dict(named=False, fuse_bn=True),
+                    dict(named=False, fuse_bn=True, shortcut_first=True, matmul_fc=True, raw_data=False),
+                    dict(named=False, eps=2e-5, shortcut_first=True, matmul_fc=True)]
+DET_ONNX_LAYOUTS = [dict(named=True), dict(named=False), dict(named=False, fuse_bn=True),
+                    dict(named=False, eps=2e-5, shortcut_first=True, laterals_first=True, raw_data=False),
+                    dict(named=False, fuse_bn=True, split_heads=True, sigmoid_scores=True)]
+
+
+@pytest.mark.parametrize("layout", range(5))
+def test_onnx_packs_reach_the_device(engine, layout):
+    """SURVEY.md 8(f-3) on the device: ONNX files as exporters write them (five embedder layouts: named / anonymous initializers,
+    BatchNorms folded into Conv / Gemm, MXNet epsilon, shortcut-first order, MatMul + Add FC, typed instead of raw tensor
+    payloads; five detector layouts: + laterals-first order, SCRFD-style split heads behind a Sigmoid) -> onnx_pack ->
+    weight blob -> frp_load_weights -> the HIP kernels, against the fp32 oracle on the SOURCE raw dict (the weights the files
+    were written from): embeddings cos >= 1 - 1e-3, head maps <= 2e-2 x scale, decode / NMS on those maps exact."""
+    from frp_amd import onnx_pack, weights
+    det_blocks, emb_blocks = (1, 2, 1, 1), (2, 1, 2, 1)
+    src = weights.make_synthetic_raw(31, det_blocks, emb_blocks)
+    det_file = onnx_pack.detector_to_onnx(src, **DET_ONNX_LAYOUTS[layout])
+    emb_file = onnx_pack.iresnet_to_onnx(src, **EMB_ONNX_LAYOUTS[layout])
+    blob = onnx_pack.pack_from_onnx(det_file, emb_file)
+    engine.load_weights(blob)
+    rng = np.random.default_rng(40 + layout)
+    # embedder
+    chips = rng.integers(0, 256, (6, 112, 112, 3), dtype=np.uint8)
+    got = engine.embed_aligned(chips)
+    ref = onet.emb_forward(src, onet.emb_blob(chips))
+    cos = (got * ref).sum(1)
+    assert cos.min() >= 1 - 1e-3, cos
+    # detector: head maps, then decode / NMS of the device's own maps
+    B, H, W = 2, 150, 200
+    canvas = ((H + 31) // 32 * 32, (W + 31) // 32 * 32)
+    frames = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    det = engine.detect(frames, max_faces=6, det_thresh=0.5)
+    heads = engine.head_maps()
+    for g, r in zip(heads, onet.det_forward(src, onet.det_blob(frames, canvas))):
+        scale = max(1.0, float(np.abs(r).max()))
+        assert g.shape[:3] == r.shape[:3] and np.abs(g[..., :30].astype(np.float32) - r).max() < 2e-2 * scale
+    for b in range(B):
+        ob, ok, osc, oa = onet.decode_nms([h[b] for h in heads], 0.5, 0.4, 6)
+        n = len(oa)
+        assert det["counts"][b] == n and np.array_equal(det["anchor_idx"][b, :n], oa) and np.array_equal(det["boxes"][b, :n], ob)
+    # the whole path on the loaded pack: detect -> align -> embed -> match against a gallery enrolled from its own embeddings
+    out = engine.process_frames(frames, max_faces=3, flags=1)
+    G = out["emb"].reshape(-1, 512)
+    engine.gallery_set(G)
+    again = engine.process_frames(frames, max_faces=3, flags=1)
+    assert np.array_equal(again["match_idx"].reshape(-1), np.arange(len(G))) and again["match_cos"].min() > 0.995
+    engine.gallery_set(np.zeros((0, 512), np.float32))

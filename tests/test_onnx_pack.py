@@ -1,4 +1,5 @@
-"""ONNX model-pack reader: wire-format round trips and IResNet mapping, CPU only."""
+"""ONNX model-pack reader: wire-format round trips, IResNet and FRPDet mapping, CPU only (the device side:
+tests/test_gpu_pipeline.py::test_onnx_packs_reach_the_device)."""
 import numpy as np
 import pytest
 
@@ -94,3 +95,73 @@ def test_structure_errors_are_reported(raw):
     bad[first_conv.inputs[1]] = np.zeros((64, 4, 3, 3), np.float32)        # 4 input channels
     with pytest.raises(ValueError, match="emb.conv1.weight"):
         onnx_pack.raw_from_onnx(onnx_pack.write_model(g.nodes, bad, g.inputs, g.outputs))
+
+
+# ----------------------------------------------------------------------------- detector (FRPDet)
+DET_BLOCKS = (1, 2, 1, 1)
+DET_LAYOUTS = [dict(), dict(named=False), dict(named=False, fuse_bn=True), dict(named=False, eps=2e-5, shortcut_first=True),
+               dict(named=False, laterals_first=True, split_heads=True, sigmoid_scores=True, raw_data=False),
+               dict(named=False, fuse_bn=True, split_heads=True, shortcut_first=True, laterals_first=True)]
+
+
+@pytest.fixture(scope="module")
+def det_raw():
+    return weights.make_synthetic_raw(13, det_blocks=DET_BLOCKS, want_emb=False)
+
+
+@pytest.mark.parametrize("kw", DET_LAYOUTS)
+def test_detector_layouts_fold_to_the_same_layers(det_raw, kw):
+    """named / anonymous initializers, BatchNorms folded by the exporter, MXNet epsilon, shortcut-first and laterals-first node
+    order, SCRFD-style split heads (+ Sigmoid on the scores): the reader follows the dataflow, and the layers the device runs
+    (fp16 weights, fp32 bias) are the source's - bit for bit where no BatchNorm was folded"""
+    back = onnx_pack.det_raw_from_onnx(onnx_pack.detector_to_onnx(det_raw, **kw))
+    assert set(back) == set(det_raw) and onnx_pack.det_blocks_of(back) == DET_BLOCKS
+    if not kw.get("fuse_bn"):
+        for k in det_raw:
+            assert np.array_equal(back[k], det_raw[k]), k
+    for l in ns.detector_layers(DET_BLOCKS):
+        (w0, b0, _), (w1, b1, _) = weights.fold_layer(det_raw, l), weights.fold_layer(back, l)
+        scale = max(1e-3, float(np.abs(w0.astype(np.float32)).max()))
+        assert np.abs(w0.astype(np.float32) - w1.astype(np.float32)).max() <= 2e-3 * scale, l.name
+        assert np.allclose(b0, b1, atol=2e-5, rtol=1e-5), l.name
+
+
+def test_loaded_detector_gives_the_same_head_maps_as_the_source_weights(det_raw):
+    from oracle import network as onet
+    back = onnx_pack.det_raw_from_onnx(onnx_pack.detector_to_onnx(det_raw, named=False, fuse_bn=True, split_heads=True, laterals_first=True))
+    frames = np.random.default_rng(5).integers(0, 256, (1, 64, 96, 3), dtype=np.uint8)
+    x = onet.det_blob(frames, (64, 96))
+    for a, b in zip(onet.det_forward(det_raw, x), onet.det_forward(back, x)):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(a).max())
+
+
+def test_detector_structure_errors_are_reported(det_raw):
+    g = onnx_pack.parse_model(onnx_pack.detector_to_onnx(det_raw, named=False))
+    with pytest.raises(ValueError, match="Relu"):
+        onnx_pack.det_raw_from_onnx(onnx_pack.write_model([n for n in g.nodes if n.op != "Relu"], g.initializers, g.inputs, g.outputs))
+    with pytest.raises(ValueError, match="nearest"):
+        nodes = [onnx_pack.Node(n.op, n.inputs, n.outputs, n.name, dict(n.attrs, mode="linear") if n.op == "Resize" else n.attrs) for n in g.nodes]
+        onnx_pack.det_raw_from_onnx(onnx_pack.write_model(nodes, g.initializers, g.inputs, g.outputs))
+    bad = dict(g.initializers)
+    first = next(n for n in g.nodes if n.op == "Conv")
+    bad[first.inputs[1]] = np.zeros((32, 4, 3, 3), np.float32)
+    with pytest.raises(ValueError, match="det.stem1.conv.weight"):
+        onnx_pack.det_raw_from_onnx(onnx_pack.write_model(g.nodes, bad, g.inputs, g.outputs))
+    # an embedder file is not a detector, and the other way round
+    emb = weights.make_synthetic_raw(11, emb_blocks=(1, 1, 1, 1), want_det=False)
+    with pytest.raises(ValueError, match="FRPDet"):
+        onnx_pack.det_raw_from_onnx(onnx_pack.iresnet_to_onnx(emb, named=False))
+    with pytest.raises(ValueError, match="IResNet"):
+        onnx_pack.raw_from_onnx(onnx_pack.detector_to_onnx(det_raw, named=False))
+
+
+def test_pack_from_onnx_builds_a_loadable_blob(det_raw, tmp_path):
+    emb = weights.make_synthetic_raw(11, emb_blocks=(1, 1, 1, 1), want_det=False)
+    d, e = tmp_path / "det.onnx", tmp_path / "emb.onnx"
+    d.write_bytes(onnx_pack.detector_to_onnx(det_raw, named=False, split_heads=True))
+    e.write_bytes(onnx_pack.iresnet_to_onnx(emb, named=False, fuse_bn=True))
+    blob = onnx_pack.pack_from_onnx(str(d), str(e))
+    both = dict(det_raw)
+    both.update(emb)
+    ref = weights.pack_blob(both, DET_BLOCKS, (1, 1, 1, 1))
+    assert len(blob) == len(ref)                    # same program, same tensor sizes (fused BNs move low bits of the embedder's weights)
