@@ -664,6 +664,48 @@ def test_conv_winograd_parity(engine, case):
     assert np.array_equal(wino.view(np.uint16), again.view(np.uint16))
 
 
+def test_conv_winograd_ring_stress(engine):
+    """The Winograd kernel's rings under timing pressure (round 4: the weight ring runs three sub-steps ahead and a slot is
+    restaged by the sub-step that computes on the fragments read from it; round 3's review: no stress configuration of its
+    own).  Several tiles per workgroup with 1, 3 and 4 channel blocks, with and without residual, ragged last tiles; 25
+    launches each while a second handle keeps the chip busy with other kernels on another stream (the hardware scheduler
+    then interleaves the workgroups of both and shifts every DMA's landing time): every launch returns the bits of the
+    first one, which agree with the direct kernel to 3 fp16 ulps of the scale."""
+    import threading
+    from frp_amd import native
+    other = native.Engine(0)
+    stop = threading.Event()
+    rng = np.random.default_rng(77)
+    xo = rng.standard_normal((9, 56, 56, 64)).astype(np.float16)
+    wo = (rng.standard_normal((64, 3, 3, 64)) / 24).astype(np.float16)
+    bo = np.zeros(64, np.float32)
+
+    def noise():
+        while not stop.is_set():
+            other.conv2d(xo, wo, bo, flags=TILES_DEFAULT)
+    th = threading.Thread(target=noise, daemon=True)
+    th.start()
+    try:
+        for (N, H, W, Cin, Cout, act, has_res, flags) in ((600, 14, 14, 256, 256, 2, False, 1), (333, 14, 14, 192, 128, 0, True, 0),
+                                                           (170, 28, 28, 64, 256, 1, True, 0), (41, 30, 30, 128, 136, 2, False, 1)):
+            x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+            w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
+            bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+            slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+            res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
+            first = engine.conv2d(x, w, bias, act=act, slope=slope, res=res, flags=flags | 0x10000)
+            direct = engine.conv2d(x, w, bias, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT)
+            scale = max(1.0, float(np.abs(direct.astype(np.float32)).max()))
+            assert np.abs(first.astype(np.float32) - direct.astype(np.float32)).max() <= 3 * 2.0 ** -10 * scale
+            for _ in range(25):
+                got = engine.conv2d(x, w, bias, act=act, slope=slope, res=res, flags=flags | 0x10000)
+                assert np.array_equal(first.view(np.uint16), got.view(np.uint16))
+    finally:
+        stop.set()
+        th.join()
+        other.close()
+
+
 def test_conv_winograd_rejects_what_it_does_not_cover(engine):
     from frp_amd.native import FrpError
     for shape, k, stride in (((1, 7, 7, 64), 3, 1), ((1, 8, 8, 32), 3, 1), ((1, 8, 8, 64), 1, 1), ((1, 8, 8, 64), 3, 2), ((1, 8, 63, 64), 3, 1), ((1, 8, 64, 64), 3, 1)):
