@@ -11,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "frp.h"
 #ifdef FRP_LAB
@@ -18,6 +20,7 @@
 #endif
 #include "frp_blob.h"
 #include "frp_internal.h"
+#include "jpeg_host.h"
 
 using namespace frp;
 
@@ -95,6 +98,12 @@ struct frp_handle {
     DevBuf gallery;
     int64_t g_rows = 0;
     DevBuf g_reserved;               // frp_gallery_reserve: filled by the caller, swapped in by frp_gallery_commit
+    // JPEG ingest (frp_upload_jpeg_async): page-locked coefficient staging, device coefficients / tables / sample planes
+    void* jpeg_pin = nullptr;
+    size_t jpeg_pin_cap = 0;
+    DevBuf jpeg_coef, jpeg_planes;
+    hipEvent_t ev_jpeg_h2d = nullptr;     // the copy out of jpeg_pin has finished
+    bool jpeg_h2d_pending = false;
     // exact compat rows (frp_gallery_exact): float64 [g_rows x 512] as enrolled, next to the unit fp16 snapshot
     bool g_exact = false;
     DevBuf gx, gx_q, gx_out;
@@ -1037,9 +1046,11 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
                      &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery,
-                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out};
+                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->jpeg_pin) (void)hipHostFree(h->jpeg_pin);
+    if (h->ev_jpeg_h2d) (void)hipEventDestroy(h->ev_jpeg_h2d);
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
     if (h->pin_stage) (void)hipHostFree(h->pin_stage);
     for (void* p : h->pinned) (void)hipHostFree(p);
@@ -1457,6 +1468,101 @@ int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_
                                hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_next_ready, h->copy_stream));
     h->nB = B; h->nH = H; h->nW = W;
+    h->next_valid = true;
+    return FRP_OK;
+}
+
+int frp_jpeg_info_get(const uint8_t* data, size_t size, frp_jpeg_info* info) {
+    if (!data || !info) return FRP_ERR_INVALID;
+    return jpeg_info(data, size, info, nullptr);
+}
+
+int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_t coef_elems, uint16_t* qtab, frp_jpeg_info* info) {
+    if (!data || !coef || !qtab) return FRP_ERR_INVALID;
+    return jpeg_decode_coefficients(data, size, coef, coef_elems, qtab, info, nullptr);
+}
+
+int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h, false);      // copy stream only (as frp_upload_frames_async)
+    if (!jpegs || !sizes || B <= 0 || B > 1024) return fail(h, FRP_ERR_INVALID, "bad JPEG batch arguments");
+    frp_jpeg_info I{};
+    std::string err;
+    if (!jpegs[0] || jpeg_info(jpegs[0], sizes[0], &I, &err) != FRP_OK) return fail(h, FRP_ERR_INVALID, "JPEG 0: " + err);
+    const size_t ce = jpeg_coef_elems(I);
+    // staging: [B] coefficients (int16) then [B][3][64] tables (uint16), 16-byte aligned parts
+    const size_t coef_bytes = (size_t)B * ce * 2, q_off = (coef_bytes + 255) & ~(size_t)255, total = q_off + (size_t)B * 3 * 64 * 2;
+    if (h->jpeg_h2d_pending) {                       // the previous batch's copy still reads the page-locked staging
+        HIPCHK(h, hipEventSynchronize(h->ev_jpeg_h2d));
+        h->jpeg_h2d_pending = false;
+    }
+    if (total > h->jpeg_pin_cap) {
+        if (h->jpeg_pin) { (void)hipHostFree(h->jpeg_pin); h->jpeg_pin = nullptr; h->jpeg_pin_cap = 0; }
+        if (hipHostMalloc(&h->jpeg_pin, total, hipHostMallocDefault) != hipSuccess) return fail(h, FRP_ERR_OOM, "hipHostMalloc (JPEG staging) failed");
+        h->jpeg_pin_cap = total;
+    }
+    if (!h->ev_jpeg_h2d) HIPCHK(h, hipEventCreateWithFlags(&h->ev_jpeg_h2d, hipEventDisableTiming));
+    int16_t* coef = (int16_t*)h->jpeg_pin;
+    uint16_t* qtab = (uint16_t*)((char*)h->jpeg_pin + q_off);
+    // entropy decoding: one image per task on host threads (the images are independent; within one the bit stream is serial)
+    std::vector<int> rcs((size_t)B, FRP_OK);
+    std::vector<std::string> errs((size_t)B);
+    {
+        const int nth = std::max(1, std::min<int>(B, (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()))));
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (int i = next.fetch_add(1); i < B; i = next.fetch_add(1)) {
+                frp_jpeg_info Ii{};
+                if (!jpegs[i]) { rcs[i] = FRP_ERR_INVALID; errs[i] = "null image"; continue; }
+                rcs[i] = jpeg_decode_coefficients(jpegs[i], sizes[i], coef + (size_t)i * ce, ce, qtab + (size_t)i * 192, &Ii, &errs[i]);
+                if (rcs[i] == FRP_OK && (Ii.width != I.width || Ii.height != I.height || Ii.components != I.components ||
+                                         Ii.h_samp[0] != I.h_samp[0] || Ii.v_samp[0] != I.v_samp[0])) {
+                    rcs[i] = FRP_ERR_INVALID;
+                    errs[i] = "geometry differs from image 0 (one batch = one frame size and sampling)";
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < B; ++i)
+        if (rcs[i] != FRP_OK) return fail(h, rcs[i], "JPEG " + std::to_string(i) + ": " + errs[i]);
+    JpegParams p{};
+    p.B = B; p.W = I.width; p.H = I.height; p.components = I.components;
+    p.hs = I.h_samp[0]; p.vs = I.v_samp[0];
+    p.cw = (I.width + p.hs - 1) / p.hs;
+    p.ch = (I.height + p.vs - 1) / p.vs;
+    long off = 0;
+    for (int c = 0; c < I.components; ++c) {
+        p.bx[c] = I.mcus_x * I.h_samp[c];
+        p.by[c] = I.mcus_y * I.v_samp[c];
+        p.blocks_per_image += p.bx[c] * p.by[c];
+        p.plane_off[c] = off;
+        off += (long)p.bx[c] * p.by[c] * 64;
+    }
+    p.plane_img = off;
+    const size_t need = (size_t)B * I.height * I.width * 3;
+    if (need > h->frames_next.cap || !h->frames_next.p || total > h->jpeg_coef.cap || (size_t)B * off > h->jpeg_planes.cap) {
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // growing buffers: nothing may still be copying into / computing from them
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        FRPCHK(ensure(h, h->frames_next, need));
+        FRPCHK(ensure(h, h->jpeg_coef, total));
+        FRPCHK(ensure(h, h->jpeg_planes, (size_t)B * off));
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_next_free, 0));     // the staging frame buffer was the resident one until the last swap
+    HIPCHK(h, hipMemcpyAsync(h->jpeg_coef.p, h->jpeg_pin, total, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_jpeg_h2d, h->copy_stream));
+    h->jpeg_h2d_pending = true;
+    p.coef = (const int16_t*)h->jpeg_coef.p;
+    p.qtab = (const uint16_t*)((const char*)h->jpeg_coef.p + q_off);
+    p.planes = (uint8_t*)h->jpeg_planes.p;
+    p.frames = (uint8_t*)h->frames_next.p;
+    hipError_t e = launch_jpeg_decode(p, h->copy_stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("jpeg decode: ") + hipGetErrorString(e));
+    HIPCHK(h, hipEventRecord(h->ev_next_ready, h->copy_stream));
+    h->nB = B; h->nH = I.height; h->nW = I.width;
     h->next_valid = true;
     return FRP_OK;
 }

@@ -137,6 +137,21 @@ struct DecodeParams {
 };
 hipError_t launch_decode_nms(const DecodeParams& p, hipStream_t stream);
 
+// JPEG ingest, device half (jpeg_kernels.hip): quantised coefficients -> BGR frames
+struct JpegParams {
+    const int16_t* coef;     // [B][blocks_per_image][64], natural order, quantised; per image the components back to back
+    const uint16_t* qtab;    // [B][3][64]
+    uint8_t* planes;         // scratch: per image the sample planes of the components ([by * 8][bx * 8] u8 each)
+    uint8_t* frames;         // out: [B, H, W, 3] u8 BGR
+    int B, W, H, components;
+    int bx[3], by[3];        // blocks per row / column of each component (whole MCUs)
+    int blocks_per_image;
+    long plane_off[3], plane_img;   // byte offsets of the component planes inside an image's scratch, bytes per image (multiples of 8)
+    int hs, vs;              // luma sampling factors (chroma 1 x 1)
+    int cw, ch;              // real extent of the chroma planes: ceil(W / hs), ceil(H / vs)
+};
+hipError_t launch_jpeg_decode(const JpegParams& p, hipStream_t stream);
+
 // u8 bilinear resize for the detection pyramid (frames [B,H,W,3] tightly packed)
 hipError_t launch_resize_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int Hs, int Ws, hipStream_t stream);
 

@@ -1,0 +1,312 @@
+// Host half of the JPEG ingest: header parsing and Huffman (entropy) decoding of BASELINE JPEG stills into
+// quantised DCT coefficients.  The device half (jpeg_kernels.hip) dequantises, runs the inverse DCT, upsamples the chroma
+// planes and converts to BGR straight into the engine's staging frame buffer.
+//
+// Replaces, for uploaded stills: `face_recognition.load_image_file` / PIL decode behind backend/app/routes/face.py:177-185,216
+// and backend/app/services/face_service.py:139 - the part of it that is inherently serial (the bit stream); everything
+// with data parallelism moves to the GPU.
+//
+// Written from the JPEG specification (ITU-T T.81): markers SOI / APPn / DQT / SOF0 / SOF1 / DHT / DRI / SOS / RSTn / EOI,
+// 8-bit samples, Huffman coding, interleaved or single-component scans that cover all coefficients (Ss = 0, Se = 63); 1 or 3
+// components.  Progressive / arithmetic / 12-bit / multi-scan files are reported as unsupported (FRP_ERR_INVALID), never
+// half-decoded.
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "frp.h"
+#include "jpeg_host.h"
+
+namespace frp {
+
+namespace {
+
+const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffTable {
+    bool present = false;
+    // canonical decoding (T.81 F.2.2.3): per code length the smallest code, the largest code and the value index of the first
+    int32_t mincode[17], maxcode[18], valptr[17];
+    uint8_t vals[256];
+    // 9-bit look-ahead: (length << 8) | value, 0 = longer than 9 bits
+    uint16_t fast[512];
+};
+
+bool build_table(HuffTable& t, const uint8_t* counts, const uint8_t* vals, int nvals) {
+    int code = 0, k = 0;
+    memset(t.fast, 0, sizeof(t.fast));
+    for (int len = 1; len <= 16; ++len) {
+        t.valptr[len] = k;
+        t.mincode[len] = code;
+        for (int i = 0; i < counts[len - 1]; ++i, ++k) {
+            if (k >= nvals) return false;
+            if (len <= 9) {
+                const int first = code << (9 - len);
+                for (int f = 0; f < (1 << (9 - len)); ++f) t.fast[first + f] = (uint16_t)((len << 8) | vals[k]);
+            }
+            ++code;
+        }
+        t.maxcode[len] = counts[len - 1] ? code - 1 : -1;
+        if (code > (1 << len)) return false;           // over-subscribed
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7fffffff;
+    memcpy(t.vals, vals, (size_t)nvals);
+    t.present = true;
+    return true;
+}
+
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0;
+    int nbits = 0;
+    bool hit_marker = false;      // a marker (other than stuffing) was reached: only zero bits are fed from here on
+    void fill() {
+        while (nbits <= 56) {
+            uint32_t b = 0;
+            if (!hit_marker && p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < end && p[1] == 0x00) p += 2;        // stuffed zero
+                    else { hit_marker = true; b = 0; }
+                } else {
+                    ++p;
+                }
+            } else {
+                hit_marker = true;
+            }
+            acc |= (uint64_t)b << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+    inline void skip(int n) { acc <<= n; nbits -= n; }
+    inline int32_t receive_extend(int s) {
+        if (s == 0) return 0;
+        if (nbits < s) fill();
+        const uint32_t v = peek(s);
+        skip(s);
+        return v < (1u << (s - 1)) ? (int32_t)v - (1 << s) + 1 : (int32_t)v;
+    }
+    inline int decode(const HuffTable& t) {
+        if (nbits < 16) fill();
+        const uint16_t f = t.fast[peek(9)];
+        if (f) { skip(f >> 8); return f & 0xff; }
+        int32_t code = (int32_t)peek(9);
+        for (int len = 10; len <= 16; ++len) {
+            code = (int32_t)peek(len);
+            if (t.maxcode[len] >= 0 && code <= t.maxcode[len] && code >= t.mincode[len]) {
+                skip(len);
+                return t.vals[t.valptr[len] + code - t.mincode[len]];
+            }
+        }
+        return -1;
+    }
+    void reset_at(const uint8_t* q) { p = q; acc = 0; nbits = 0; hit_marker = false; }
+};
+
+inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+}  // namespace
+
+struct JpegHeaderInternal {
+    frp_jpeg_info info{};
+    uint16_t qt[4][64];          // natural order
+    bool have_qt[4] = {false, false, false, false};
+    HuffTable dc[4], ac[4];
+    int comp_id[3], comp_tq[3], comp_td[3], comp_ta[3];
+    const uint8_t* scan = nullptr;     // first entropy-coded byte
+    std::string err;
+};
+
+static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) { H.err = "not a JPEG (no SOI)"; return FRP_ERR_INVALID; }
+    size_t pos = 2;
+    bool have_sof = false;
+    frp_jpeg_info& I = H.info;
+    while (pos + 4 <= n) {
+        if (d[pos] != 0xFF) { H.err = "marker expected"; return FRP_ERR_INVALID; }
+        while (pos < n && d[pos] == 0xFF) ++pos;                     // fill bytes
+        if (pos >= n) break;
+        const int m = d[pos++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) break;
+        if (pos + 2 > n) break;
+        const int len = be16(d + pos);
+        if (len < 2 || pos + (size_t)len > n) { H.err = "truncated segment"; return FRP_ERR_INVALID; }
+        const uint8_t* s = d + pos + 2;
+        const int sl = len - 2;
+        if (m == 0xDB) {                                              // DQT
+            int o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                ++o;
+                if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) { H.err = "bad DQT"; return FRP_ERR_INVALID; }
+                for (int i = 0; i < 64; ++i) {
+                    const int v = pq ? be16(s + o + 2 * i) : s[o + i];
+                    H.qt[tq][kZigZag[i]] = (uint16_t)v;
+                }
+                o += pq ? 128 : 64;
+                H.have_qt[tq] = true;
+            }
+        } else if (m == 0xC4) {                                       // DHT
+            int o = 0;
+            while (o + 17 <= sl) {
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                int total = 0;
+                for (int i = 0; i < 16; ++i) total += s[o + 1 + i];
+                if (tc > 1 || th > 3 || total > 256 || o + 17 + total > sl) { H.err = "bad DHT"; return FRP_ERR_INVALID; }
+                if (!build_table(tc ? H.ac[th] : H.dc[th], s + o + 1, s + o + 17, total)) { H.err = "bad Huffman table"; return FRP_ERR_INVALID; }
+                o += 17 + total;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {                          // SOF0 / SOF1: sequential Huffman
+            if (sl < 6 || s[0] != 8) { H.err = "only 8-bit samples are supported"; return FRP_ERR_INVALID; }
+            I.height = be16(s + 1);
+            I.width = be16(s + 3);
+            I.components = s[5];
+            if (!(I.components == 1 || I.components == 3) || sl < 6 + 3 * I.components || I.width <= 0 || I.height <= 0) {
+                H.err = "unsupported component count or size";
+                return FRP_ERR_INVALID;
+            }
+            int hmax = 1, vmax = 1;
+            for (int c = 0; c < I.components; ++c) {
+                H.comp_id[c] = s[6 + 3 * c];
+                I.h_samp[c] = s[7 + 3 * c] >> 4;
+                I.v_samp[c] = s[7 + 3 * c] & 15;
+                H.comp_tq[c] = s[8 + 3 * c];
+                if (I.h_samp[c] < 1 || I.h_samp[c] > 2 || I.v_samp[c] < 1 || I.v_samp[c] > 2 || H.comp_tq[c] > 3) {
+                    H.err = "unsupported sampling factors";
+                    return FRP_ERR_INVALID;
+                }
+                hmax = I.h_samp[c] > hmax ? I.h_samp[c] : hmax;
+                vmax = I.v_samp[c] > vmax ? I.v_samp[c] : vmax;
+            }
+            if (I.components == 3 && (I.h_samp[1] != 1 || I.v_samp[1] != 1 || I.h_samp[2] != 1 || I.v_samp[2] != 1 ||
+                                      (I.h_samp[0] == 1 && I.v_samp[0] == 2))) {
+                H.err = "unsupported chroma subsampling (4:4:4, 4:2:2 and 4:2:0 files are covered)";
+                return FRP_ERR_INVALID;
+            }
+            if (I.components == 1) { I.h_samp[0] = I.v_samp[0] = 1; hmax = vmax = 1; }     // a single component is never interleaved
+            I.mcus_x = (I.width + 8 * hmax - 1) / (8 * hmax);
+            I.mcus_y = (I.height + 8 * vmax - 1) / (8 * vmax);
+            have_sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            H.err = "progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)";
+            I.progressive = 1;
+            return FRP_ERR_INVALID;
+        } else if (m == 0xDD) {                                       // DRI
+            if (sl < 2) { H.err = "bad DRI"; return FRP_ERR_INVALID; }
+            I.restart_interval = be16(s);
+        } else if (m == 0xDA) {                                       // SOS
+            if (!have_sof) { H.err = "SOS before SOF"; return FRP_ERR_INVALID; }
+            const int ns = s[0];
+            if (ns != I.components || sl < 1 + 2 * ns + 3) { H.err = "multi-scan files are not supported"; return FRP_ERR_INVALID; }
+            for (int c = 0; c < ns; ++c) {
+                if (s[1 + 2 * c] != H.comp_id[c]) { H.err = "scan component order differs from the frame's"; return FRP_ERR_INVALID; }
+                H.comp_td[c] = s[2 + 2 * c] >> 4;
+                H.comp_ta[c] = s[2 + 2 * c] & 15;
+                if (H.comp_td[c] > 3 || H.comp_ta[c] > 3 || !H.dc[H.comp_td[c]].present || !H.ac[H.comp_ta[c]].present || !H.have_qt[H.comp_tq[c]]) {
+                    H.err = "scan refers to a table the file does not define";
+                    return FRP_ERR_INVALID;
+                }
+            }
+            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63) { H.err = "spectral selection is not supported (baseline only)"; return FRP_ERR_INVALID; }
+            H.scan = d + pos + len;
+            return FRP_OK;
+        }
+        pos += (size_t)len;
+    }
+    H.err = "no scan found";
+    return FRP_ERR_INVALID;
+}
+
+size_t jpeg_coef_elems(const frp_jpeg_info& I) {
+    size_t e = 0;
+    for (int c = 0; c < I.components; ++c) e += (size_t)I.mcus_x * I.h_samp[c] * I.mcus_y * I.v_samp[c] * 64;
+    return e;
+}
+
+int jpeg_info(const uint8_t* data, size_t size, frp_jpeg_info* out, std::string* err) {
+    JpegHeaderInternal H;
+    const int rc = parse_headers(data, size, H);
+    if (out) *out = H.info;
+    if (rc != FRP_OK && err) *err = H.err;
+    return rc;
+}
+
+// Entropy-decode every block.  coef: per component a [blocks_y][blocks_x][64] int16 array (natural order, NOT dequantised),
+// components back to back; qtab_out: [3][64] uint16 quantisation steps in natural order.
+int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_t coef_elems, uint16_t* qtab_out, frp_jpeg_info* info_out,
+                             std::string* err) {
+    JpegHeaderInternal H;
+    int rc = parse_headers(data, size, H);
+    if (info_out) *info_out = H.info;
+    if (rc != FRP_OK) { if (err) *err = H.err; return rc; }
+    const frp_jpeg_info& I = H.info;
+    if (!coef || coef_elems < jpeg_coef_elems(I)) { if (err) *err = "coefficient buffer too small"; return FRP_ERR_INVALID; }
+    memset(coef, 0, jpeg_coef_elems(I) * sizeof(int16_t));
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 64; ++i) qtab_out[c * 64 + i] = c < I.components ? H.qt[H.comp_tq[c]][i] : 1;
+    int16_t* base[3];
+    int bx[3], by[3];
+    size_t off = 0;
+    for (int c = 0; c < I.components; ++c) {
+        bx[c] = I.mcus_x * I.h_samp[c];
+        by[c] = I.mcus_y * I.v_samp[c];
+        base[c] = coef + off;
+        off += (size_t)bx[c] * by[c] * 64;
+    }
+    BitReader br;
+    br.reset_at(H.scan);
+    br.end = data + size;
+    int pred[3] = {0, 0, 0};
+    int restart_left = I.restart_interval, next_rst = 0;
+    for (int my = 0; my < I.mcus_y; ++my)
+        for (int mx = 0; mx < I.mcus_x; ++mx) {
+            if (I.restart_interval && restart_left == 0) {
+                // byte-align, expect RSTn
+                const uint8_t* q = br.p;
+                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;       // (br.p sits at or before the marker)
+                if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) { if (err) *err = "restart marker missing or out of sequence"; return FRP_ERR_INVALID; }
+                br.reset_at(q + 2);
+                next_rst = (next_rst + 1) & 7;
+                pred[0] = pred[1] = pred[2] = 0;
+                restart_left = I.restart_interval;
+            }
+            for (int c = 0; c < I.components; ++c) {
+                const HuffTable& dct = H.dc[H.comp_td[c]];
+                const HuffTable& act = H.ac[H.comp_ta[c]];
+                for (int v = 0; v < I.v_samp[c]; ++v)
+                    for (int hh = 0; hh < I.h_samp[c]; ++hh) {
+                        int16_t* blk = base[c] + ((size_t)(my * I.v_samp[c] + v) * bx[c] + (mx * I.h_samp[c] + hh)) * 64;
+                        const int s = br.decode(dct);
+                        if (s < 0 || s > 11) { if (err) *err = "corrupt DC code"; return FRP_ERR_INVALID; }
+                        pred[c] += br.receive_extend(s);
+                        blk[0] = (int16_t)pred[c];
+                        for (int k = 1; k < 64;) {
+                            const int rs = br.decode(act);
+                            if (rs < 0) { if (err) *err = "corrupt AC code"; return FRP_ERR_INVALID; }
+                            const int r = rs >> 4, sz = rs & 15;
+                            if (sz == 0) {
+                                if (r == 15) { k += 16; continue; }
+                                break;                                 // end of block
+                            }
+                            k += r;
+                            if (k > 63) { if (err) *err = "corrupt AC run"; return FRP_ERR_INVALID; }
+                            blk[kZigZag[k]] = (int16_t)br.receive_extend(sz);
+                            ++k;
+                        }
+                        if (br.hit_marker && br.nbits < 0) { if (err) *err = "scan data ends early"; return FRP_ERR_INVALID; }
+                    }
+            }
+            if (I.restart_interval) --restart_left;
+        }
+    return FRP_OK;
+}
+
+}  // namespace frp

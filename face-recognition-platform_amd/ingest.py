@@ -1,4 +1,10 @@
-"""Image ingest for the REST upload paths (first step): encoded stills -> device frames.
+"""Image ingest for the REST upload paths: encoded stills -> device frames.
+
+Baseline JPEG uploads (what phone cameras and browsers send; routes/face.py:177-185 receives them as bytes) are decoded ON
+THE WAY to the device (round 4): their bit streams - the serial part - on host threads inside `frp_upload_jpeg_async`, the
+dequantisation, inverse DCT, chroma upsampling and colour conversion by HIP kernels on the engine's copy stream, straight into
+the staging frame buffer, bit for bit what PIL would have decoded (`device_jpeg_batch` decides per batch; anything else - PNG,
+progressive JPEG, mixed sizes, a short last batch - takes the host path below).
 
 The reference decodes every upload with PIL (`face_recognition.load_image_file`, routes/face.py:216,404,976) into a
 pageable array, which a naive port would hand to hipMemcpy: the runtime then bounces it through its own staging buffer
@@ -34,6 +40,30 @@ def decode_rgb(src: Source, hw: Tuple[int, int]) -> np.ndarray:
     return img
 
 
+def device_jpeg_batch(sources: Sequence[Source], batch: int, hw: Tuple[int, int]):
+    """-> the batch as a list of JPEG byte strings when the device decoder covers ALL of it (a full batch of baseline JPEG
+    stills of the staging buffer's size and one chroma sampling), else None"""
+    if len(sources) != batch:
+        return None
+    out, sampling = [], None
+    for s in sources:
+        if isinstance(s, np.ndarray):
+            return None
+        if isinstance(s, str):
+            with open(s, "rb") as f:
+                s = f.read()
+        s = bytes(s)
+        info = native.jpeg_info(s)
+        if info is None or (info["height"], info["width"]) != tuple(hw):
+            return None
+        key = (info["components"], info["h_samp"][0], info["v_samp"][0])
+        if sampling is not None and key != sampling:
+            return None
+        sampling = key
+        out.append(s)
+    return out
+
+
 def batched(sources: Sequence[Source], batch: int) -> Iterator[Sequence[Source]]:
     """an upload of any length as consecutive batches of at most `batch` stills (what StagedIngest.run consumes)"""
     for i in range(0, len(sources), batch):
@@ -43,9 +73,23 @@ def batched(sources: Sequence[Source], batch: int) -> Iterator[Sequence[Source]]
 class StagedIngest:
     """Two page-locked staging buffers of B x H x W RGB frames on one engine."""
 
-    def __init__(self, engine, batch: int, height: int, width: int):
+    def __init__(self, engine, batch: int, height: int, width: int, device_jpeg: bool = True):
         self.eng, self.B, self.H, self.W = engine, batch, height, width
         self._stage = [engine.host_frames(batch, height, width) for _ in range(2)]
+        self.device_jpeg = device_jpeg and hasattr(engine, "upload_jpeg_async")
+        self.device_decoded = 0            # batches that took the device decoder
+
+    def _stage_batch(self, slot: int, sources: Sequence[Source]) -> Tuple[int, int]:
+        """bring one batch into the engine's staging frame buffer -> (real frames, process flags for it): JPEG batches are
+        decoded on the way (BGR frames, no flag), everything else by PIL into page-locked staging (RGB frames)"""
+        jp = device_jpeg_batch(sources, self.B, (self.H, self.W)) if self.device_jpeg else None
+        if jp is not None:
+            self.eng.upload_jpeg_async(jp)
+            self.device_decoded += 1
+            return len(jp), 0
+        n = self.decode_into(slot, sources)
+        self.eng.upload_frames_async(self._stage[slot])
+        return n, native.FLAG_RGB
 
     def decode_into(self, slot: int, sources: Sequence[Source]) -> int:
         """decode up to B stills into staging buffer `slot`; frames beyond len(sources) are zeroed.  -> count.
@@ -65,26 +109,23 @@ class StagedIngest:
         """detect + embed + match every batch of stills; yields (number of real frames, result dict) per batch.
         Decode and upload of batch t+1 overlap the GPU work of batch t."""
         eng = self.eng
-        flags |= native.FLAG_RGB
         it = iter(batches)
         with eng.sequence():
             first = next(it, None)
             if first is None:
                 return
-            n_cur = self.decode_into(0, first)
-            eng.upload_frames_async(self._stage[0])
+            n_cur, fl_cur = self._stage_batch(0, first)
             eng.swap_frames()
             slot = 1
             while True:
                 nxt = next(it, None)
-                eng.process_resident(max_faces, det_thresh=det_thresh, nms_iou=nms_iou, flags=flags)   # asynchronous
-                n_next = 0
+                eng.process_resident(max_faces, det_thresh=det_thresh, nms_iou=nms_iou, flags=flags | fl_cur)   # asynchronous
+                n_next = fl_next = 0
                 if nxt is not None:
-                    n_next = self.decode_into(slot, nxt)          # host decode while the GPU works
-                    eng.upload_frames_async(self._stage[slot])    # copy stream: overlaps the running pass
-                out = eng.fetch_results()                         # waits for the pass
+                    n_next, fl_next = self._stage_batch(slot, nxt)   # host decode / entropy decode while the GPU works; the copy
+                out = eng.fetch_results()                            # (and the device half of a JPEG decode) overlap the running pass
                 yield n_cur, out
                 if nxt is None:
                     return
                 eng.swap_frames()
-                n_cur, slot = n_next, slot ^ 1
+                n_cur, fl_cur, slot = n_next, fl_next, slot ^ 1

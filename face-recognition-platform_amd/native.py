@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -30,6 +30,7 @@ F32, F16, F64 = 0, 1, 2
 ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_cancel", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
+    "frp_jpeg_info_get", "frp_jpeg_coefficients", "frp_upload_jpeg_async",
     "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
@@ -55,6 +56,40 @@ class FrpCounters(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("reserved", "struct_size")}
+
+
+class JpegInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("h_samp", C.c_int32 * 3), ("v_samp", C.c_int32 * 3),
+                ("mcus_x", C.c_int32), ("mcus_y", C.c_int32), ("restart_interval", C.c_int32), ("progressive", C.c_int32)]
+
+    def as_dict(self) -> dict:
+        return {"width": self.width, "height": self.height, "components": self.components, "h_samp": list(self.h_samp),
+                "v_samp": list(self.v_samp), "mcus_x": self.mcus_x, "mcus_y": self.mcus_y, "restart_interval": self.restart_interval}
+
+
+def jpeg_info(data: bytes):
+    """header of a baseline JPEG as the library's decoder sees it, or None when it does not cover the file (progressive,
+    arithmetic-coded, 12-bit, CMYK, multi-scan): include/frp.h frp_jpeg_info_get.  Needs no GPU."""
+    info = JpegInfo()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    rc = load_library().frp_jpeg_info_get(C.cast(buf, C.c_void_p), len(data), C.byref(info))
+    return info.as_dict() if rc == 0 else None
+
+
+def jpeg_coefficients(data: bytes):
+    """host entropy decode alone (parity tests): -> (info dict, int16 coefficients, uint16 [3, 64] tables)"""
+    info = jpeg_info(data)
+    if info is None:
+        raise FrpError(-1, "not a baseline JPEG the decoder covers")
+    n = sum(info["mcus_x"] * info["h_samp"][c] * info["mcus_y"] * info["v_samp"][c] * 64 for c in range(info["components"]))
+    coef = np.zeros(n, np.int16)
+    q = np.zeros((3, 64), np.uint16)
+    ji = JpegInfo()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    rc = load_library().frp_jpeg_coefficients(C.cast(buf, C.c_void_p), len(data), _ptr(coef), n, _ptr(q), C.byref(ji))
+    if rc != 0:
+        raise FrpError(rc, "corrupt JPEG scan data")
+    return info, coef, q
 
 
 class FrpError(RuntimeError):
@@ -109,6 +144,9 @@ def load_library() -> C.CDLL:
     lib.frp_gallery_size.argtypes = [vp]
     lib.frp_gallery_size.restype = i64
     lib.frp_gallery_get.argtypes = [vp, vp, i64, i64]
+    lib.frp_jpeg_info_get.argtypes = [vp, C.c_size_t, vp]
+    lib.frp_jpeg_coefficients.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp]
+    lib.frp_upload_jpeg_async.argtypes = [vp, vp, vp, i32]
     lib.frp_gallery_exact.argtypes = [vp, i32]
     lib.frp_gallery_distances.argtypes = [vp, vp, i32, vp, i64]
     lib.frp_gallery_get_exact.argtypes = [vp, vp, i64, i64]
@@ -244,6 +282,18 @@ class Engine:
     def gallery_update_row(self, row: int, emb: np.ndarray):
         e, code = self._row512(emb)
         self._chk(self._lib.frp_gallery_update_row(self._h, row, _ptr(e), e.shape[0], code))
+
+    def upload_jpeg_async(self, jpegs: Sequence[bytes]):
+        """B baseline JPEG stills of one geometry -> the staging frame buffer, decoded on the way: the bit streams on host
+        threads, dequantisation / inverse DCT / chroma upsampling / YCbCr -> BGR on the GPU's copy stream (frp.h:
+        frp_upload_jpeg_async).  Follow with swap_frames() as after upload_frames_async()."""
+        B = len(jpegs)
+        bufs = [(C.c_char * len(j)).from_buffer_copy(j) for j in jpegs]
+        ptrs = (C.c_void_p * B)(*[C.cast(b, C.c_void_p) for b in bufs])
+        sizes = (C.c_size_t * B)(*[len(j) for j in jpegs])
+        self._chk(self._lib.frp_upload_jpeg_async(self._h, ptrs, sizes, B))
+        info = jpeg_info(jpegs[0])
+        self._staged = (B, info["height"], info["width"])
 
     def gallery_exact(self, on: bool = True):
         """keep every row also as float64, as enrolled (frp.h: frp_gallery_exact): the rows behind gallery_distances"""

@@ -183,6 +183,29 @@ void frp_host_free(frp_handle* h, void* p);
 int frp_upload_frames_async(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride);
 int frp_swap_frames(frp_handle* h);
 
+/* ---- encoded stills ------------------------------------------------------
+ * replaces: the image decode behind the upload routes - face_recognition.load_image_file (PIL) at
+ * backend/app/services/face_service.py:139 and backend/app/routes/face.py:177-185,216,404,976.  Baseline JPEG (8-bit, Huffman,
+ * one interleaved scan; grayscale, 4:4:4, 4:2:2, 4:2:0): the bit stream - the one serial part - is decoded on host threads
+ * into quantised DCT coefficients in page-locked memory; dequantisation, the inverse DCT (the integer "slow" algorithm of
+ * libjpeg, bit for bit), the triangle-filter chroma upsampling and YCbCr -> BGR run on the GPU, on the handle's copy stream,
+ * and write the staging frame buffer of frp_upload_frames_async.  Progressive / arithmetic-coded / 12-bit files are refused. */
+typedef struct frp_jpeg_info {
+    int32_t width, height, components;      /* 1 (grayscale) or 3 (YCbCr) */
+    int32_t h_samp[3], v_samp[3];           /* sampling factors per component (chroma always 1 x 1) */
+    int32_t mcus_x, mcus_y;                 /* MCU grid (MCU = 8 h_samp[0] x 8 v_samp[0] pixels) */
+    int32_t restart_interval, progressive;
+} frp_jpeg_info;
+/* header only; needs no handle.  FRP_ERR_INVALID for what the decoder does not cover. */
+int frp_jpeg_info_get(const uint8_t* data, size_t size, frp_jpeg_info* info);
+/* host entropy decode alone (parity tests, no handle): coef = per component [blocks_y][blocks_x][64] int16 in natural order,
+ * quantised, components back to back (blocks_x = mcus_x * h_samp[c], blocks_y = mcus_y * v_samp[c]); qtab [3][64] */
+int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_t coef_elems, uint16_t* qtab, frp_jpeg_info* info);
+/* B stills of identical geometry -> the staging frame buffer [B, height, width, 3] u8 BGR (grayscale: replicated), as
+ * frp_upload_frames_async does for raw frames: follow with frp_swap_frames.  Returns when the coefficients are staged; the
+ * device half runs asynchronously on the copy stream. */
+int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B);
+
 /* ---- stage entry points (REST paths and parity tests) ------------------------------- */
 /* detection only -> face_recognition.face_locations (camera.py:232) */
 int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,

@@ -915,3 +915,91 @@ def test_onnx_packs_reach_the_device(engine, layout):
     again = engine.process_frames(frames, max_faces=3, flags=1)
     assert np.array_equal(again["match_idx"].reshape(-1), np.arange(len(G))) and again["match_cos"].min() > 0.995
     engine.gallery_set(np.zeros((0, 512), np.float32))
+
+
+def test_jpeg_stills_decode_on_the_device(engine):
+    """baseline JPEG stills -> frp_upload_jpeg_async (entropy decoding on host threads, dequantisation /
+    inverse DCT / chroma upsampling / YCbCr -> BGR by HIP kernels on the copy stream) -> the resident frame buffer, against
+    the decode the reference performs (PIL: face_recognition.load_image_file, face_service.py:139): EQUAL, bit for bit, on the
+    committed stills (4:2:0 / 4:2:2 / 4:4:4 / grayscale, odd sizes, optimised tables, restart intervals) and on camera-size
+    stills written on the spot; mixed geometry and files outside the decoder's scope are refused."""
+    import glob
+    import io
+    import os
+    from PIL import Image
+    from frp_amd.native import FrpError
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+
+    def device_decode(jpegs):
+        engine.upload_jpeg_async(jpegs)
+        engine.swap_frames()
+        info = __import__("frp_amd").native.jpeg_info(jpegs[0])
+        engine.detect_resident((info["height"], info["width"]), max_faces=2, det_thresh=0.5)
+        return engine.det_source()
+
+    def pil_bgr(data):
+        return np.array(Image.open(io.BytesIO(data)).convert("RGB"))[..., ::-1]
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    stills = sorted(glob.glob(os.path.join(here, "golden", "stills", "*.jpg")))
+    assert len(stills) == 8
+    for path in stills:
+        data = open(path, "rb").read()
+        got = device_decode([data, data, data])                              # a batch of three: every image of it
+        ref = pil_bgr(data)
+        assert got.shape == (3,) + ref.shape
+        for b in range(3):
+            assert np.array_equal(got[b], ref), (os.path.basename(path), int(np.abs(got[b].astype(int) - ref).max()))
+    rng = np.random.default_rng(9)
+    for (h, w, kw) in ((1080, 1920, dict(quality=88)), (720, 1280, dict(quality=95, subsampling=0)), (481, 643, dict(quality=70, subsampling=1))):
+        imgs = []
+        for i in range(2):
+            base = rng.normal(120, 50, (h // 16 + 1, w // 16 + 1, 3)).repeat(16, 0).repeat(16, 1)[:h, :w]
+            b = io.BytesIO()
+            Image.fromarray(np.clip(base + rng.normal(0, 5, (h, w, 3)), 0, 255).astype(np.uint8)).save(b, "JPEG", **kw)
+            imgs.append(b.getvalue())
+        got = device_decode(imgs)
+        for b in range(2):
+            assert np.array_equal(got[b], pil_bgr(imgs[b])), (h, w, kw)
+    # refused, nothing staged: mixed geometry, a progressive file, not a JPEG
+    small = open(stills[0], "rb").read()
+    with pytest.raises(FrpError, match="geometry"):
+        engine.upload_jpeg_async([imgs[0], small])
+    b = io.BytesIO()
+    Image.fromarray(np.zeros((32, 32, 3), np.uint8)).save(b, "JPEG", progressive=True)
+    with pytest.raises(FrpError, match="progressive"):
+        engine.upload_jpeg_async([b.getvalue()])
+    with pytest.raises(FrpError):
+        engine.upload_jpeg_async([b"not a jpeg at all"])
+
+
+def test_staged_ingest_takes_the_device_decoder_for_jpeg_batches(engine):
+    """ingest.StagedIngest: full batches of baseline JPEG stills are decoded on the way to the device, the short last batch and
+    a PNG batch by PIL on the host - and every batch gives the results of process_frames on the PIL-decoded frames"""
+    import io
+    from PIL import Image
+    from frp_amd import native
+    from frp_amd.ingest import StagedIngest
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(23)
+    engine.gallery_set(rng.standard_normal((200, 512)).astype(np.float32))
+    H, W, B = 120, 168, 3
+    srcs, decoded = [], []
+    for i in range(8):
+        img = np.clip(rng.normal(120, 40, (H // 8, W // 8, 3)).repeat(8, 0).repeat(8, 1) + rng.normal(0, 4, (H, W, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "PNG" if 3 <= i < 6 else "JPEG", quality=90)
+        srcs.append(b.getvalue())
+        decoded.append(np.array(Image.open(io.BytesIO(b.getvalue())).convert("RGB")))
+    ing = StagedIngest(engine, B, H, W)
+    got = list(ing.run([srcs[0:3], srcs[3:6], srcs[6:8]], max_faces=4, flags=native.FLAG_FORCED_K))
+    assert [n for n, _ in got] == [3, 3, 2] and ing.device_decoded == 1            # JPEG x 3 on the device; PNG x 3 and the short JPEG batch on the host
+    k = 0
+    for n, out in got:
+        ref = engine.process_frames(np.stack(decoded[k:k + n]), max_faces=4, flags=native.FLAG_FORCED_K | native.FLAG_RGB)
+        for key in ("boxes", "kps", "emb", "match_idx", "match_cos", "counts"):
+            assert np.array_equal(out[key][:n], ref[key]), key
+        k += n
+    engine.gallery_set(np.zeros((0, 512), np.float32))
