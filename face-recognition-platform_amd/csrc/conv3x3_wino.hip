@@ -667,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     half8 U[2][8];                             // [sub-step parity][frequency * 2 + cout block]: weight fragments
     half8 V[2][4];                             // [sub-step parity][frequency]: B^T d
     half8 raw[4];                              // raw pixel fragments of the next sub-step (dead after B^T d)
+    unsigned rad[4];                           // raw-fragment addresses (kk = 0) of the kernel row the next reads belong to
 
     float* lds_bias = reinterpret_cast<float*>(smem + OFF_PAR);            // [9][TC]
     float* lds_slope = lds_bias + 9 * TC;                                   // [TC]
@@ -762,6 +763,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         const int c0 = (ct - ptile * p.n_ctiles) * TC;
         make_tile(ct + tstep, nt);
         asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(lane_e));
+        // Raw-fragment addresses of the tile, once: the patch-slot-independent part (or the zero block for taps off the image) and a bit
+        // per address that says which kind it is; a kernel row's four addresses are then slot offset + base where the bit is set
+        // (per kernel row and channel block the full address arithmetic - row, swizzle, two selects - was ~130 vector
+        // instructions per channel block).
+        unsigned abase[3][4], okm = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned mask = cur.vmask;
+                const int row = pair0 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+                const int a_ = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+                const bool rowok = (mask & 1u) && (kh == 0 ? (mask & 2u) : kh == 2 ? (mask & 4u) : true);
+                const bool ok = rowok && (i == 0 ? (mask & 8u) : i == 3 ? (mask & 16u) : true);
+                abase[kh][i] = lds0 + (ok ? a_ : OFF_Z + (a_ & 255));
+                okm |= (ok ? 1u : 0u) << (kh * 4 + i);
+            }
+        auto rad_of = [&](int kh, int xslot) {          // -> rad[0..3]: this lane's raw-fragment addresses for kernel row kh in patch slot xslot
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rad[i] = abase[kh][i] + ((okm >> (kh * 4 + i)) & 1u ? (unsigned)xslot : 0u);
+        };
+        rad_of(0, xs);
         if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 2); }
 
         for (int cb = 0; cb < cpt; ++cb) {
@@ -772,13 +795,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             // per-block operands of the pinned statements (fr_e opaque per block: hoisted out of the loop, both patch slots' variants
             // of the 16 addresses cost 28 registers and spilled)
             asm volatile("" : "+v"(fr_e));
-            unsigned radr[3][4], rnx[4];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) radr[kh][i] = raw_addr(cur.vmask, kh, i, xs);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rnx[i] = raw_addr(last_cb ? nt.vmask : cur.vmask, 0, i, xs ^ XSLOT);
             const unsigned xb = nxm0b == DEAD ? 0x80000000u : (unsigned)(nxm0b + (last_cb ? 0 : (cb + 1) << 7) + xlane);
             const unsigned lx = lds0 + (xs ^ XSLOT) + wave * 1024;          // next patch: row group wave (+ NDW j)
             const unsigned lw = lds0 + OFF_W + wave * 1024;                 // weight ring: piece wave (+ NDW j) of a slot
@@ -829,14 +845,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
                 // (T = 11 of a tile's last channel block requests the next tile's first operands like any other sub-step, but nothing is
                 // KEPT across the epilogue: fragments held there - 48 registers, or 24 for B^T d and two weight fragments - spilled
                 // in it and cost more than requesting them again behind it; the dead requests cost nothing)
+                // the next sub-step's kernel row changes behind T = 3, 7, 11 (11: row 0 of the next channel block, in the other patch slot;
+                // behind a tile's last block those requests are dead, whatever they read)
+                if constexpr (KKN == 0) rad_of(KHN, T == 11 ? xs ^ XSLOT : xs);
                 {
-                    const unsigned a0 = T == 11 ? rnx[0] : radr[KHN][0] ^ (KKN << 5), a1 = T == 11 ? rnx[1] : radr[KHN][1] ^ (KKN << 5);
+                    const unsigned a0 = rad[0] ^ (KKN << 5), a1 = rad[1] ^ (KKN << 5);
                     wn2_read<0>(raw[0], a0);
                     wn2_read<0>(raw[1], a1);
                 }
                 wn2_mfma(acc[0][1], U[P][1], V[P][0]);
                 {
-                    const unsigned a2 = T == 11 ? rnx[2] : radr[KHN][2] ^ (KKN << 5), a3 = T == 11 ? rnx[3] : radr[KHN][3] ^ (KKN << 5);
+                    const unsigned a2 = rad[2] ^ (KKN << 5), a3 = rad[3] ^ (KKN << 5);
                     wn2_read<0>(raw[2], a2);
                     wn2_read<0>(raw[3], a3);
                 }

@@ -5,7 +5,7 @@
 # microarchitecture guide prescribes) summarised per kernel family, SQ counters of the stage-3 conv shape.
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/${1:-r3final}
+O=$R/gpurun_out/${1:-r4final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
