@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (0 = skip); the default is ~10-15 s of CPU work")
     ap.add_argument("--pcie-steps", type=int, default=-1,
                     help="steps of the host-to-host side measurement (-1 = as many as --steps, 0 = skip)")
+    ap.add_argument("--jpeg-steps", type=int, default=-1,
+                    help="steps of the JPEG-bytes-in side measurement on the lanes (-1 = as many as --steps, 0 = skip)")
     ap.add_argument("--threshold-steps", type=int, default=-1,
                     help="steps of the threshold-mode (NMS on, ragged face counts) side measurement (-1 = --steps, 0 = skip)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -533,6 +535,57 @@ def main():
         h2h_lanes = {"faces_per_s": round(n_h * B * K / dt_h, 1), "ms_per_step": round(dt_h / n_h * 1e3, 3), "steps": n_h,
                      "mode": f"{L} lanes, each running the overlapped-ingest loop (page-locked host frames, H2D on the lane's copy "
                              "stream under the kernels of both lanes, host results out every step)"}
+    # JPEG bytes in (never `value`): every step hands the lane a batch of baseline JPEG stills of the same frames
+    # (what routes/face.py:177-185 receives); frp_upload_jpeg_async decodes the bit streams on host threads while the lane's
+    # kernels of the current batch run, the pixels are produced on the copy stream.  Detection runs on the DECODED frames
+    # (lossy: not the same pixels as the resident batch), forced K as everywhere in this bench.
+    jpeg_lanes = None
+    if L > 1 and args.jpeg_steps != 0 and rank == 0:
+        try:
+            import io
+            from PIL import Image
+            n_j = args.steps if args.jpeg_steps < 0 else args.jpeg_steps
+            jpegs = []
+            for f_ in frames:
+                b_ = io.BytesIO()
+                Image.fromarray(np.ascontiguousarray(f_[..., ::-1])).save(b_, "JPEG", quality=90)
+                jpegs.append(b_.getvalue())
+            for e_ in lanes:
+                e_.upload_jpeg_async(jpegs)
+                e_.swap_frames()
+                e_.process_resident(K, flags=flags)
+                e_.fetch_results()
+
+            def lane_loop_jpeg(i, counter):
+                while True:
+                    with counter["lock"]:
+                        if counter["next"] >= n_j:
+                            return
+                        counter["next"] += 1
+                    lanes[i].process_resident(K, flags=flags)
+                    lanes[i].upload_jpeg_async(jpegs)                    # next batch: host entropy decode under this batch's kernels
+                    last[i] = lanes[i].fetch_results()
+                    lanes[i].swap_frames()
+
+            for e_ in lanes:
+                e_.upload_jpeg_async(jpegs)
+                e_.swap_frames()
+                e_.synchronize()
+            counter = {"next": 0, "lock": threading.Lock()}
+            t_j = time.perf_counter()
+            join_lanes([threading.Thread(target=guarded(lane_loop_jpeg), args=(i, counter)) for i in range(L)])
+            for e_ in lanes:
+                e_.synchronize()
+            dt_j = time.perf_counter() - t_j
+            jpeg_lanes = {"faces_per_s": round(n_j * B * K / dt_j, 1), "frames_per_s": round(n_j * B / dt_j, 1),
+                          "ms_per_step": round(dt_j / n_j * 1e3, 3), "steps": n_j,
+                          "jpeg_bytes_per_frame": int(sum(map(len, jpegs)) / len(jpegs)),
+                          "mode": f"{L} lanes; baseline JPEG bytes in (quality 90, 4:2:0), bit streams decoded on <= 16 host threads per "
+                                  "lane under the lane's kernels, IDCT / upsampling / colour on the copy stream, host results out every step"}
+            for e_ in lanes:
+                e_.upload_frames(frames)
+        except ImportError:
+            jpeg_lanes = None
     # Threshold mode on the lanes (never `value`): score threshold + NMS + ragged face counts, the path the reference's
     # loop runs; one lane's mid-pipeline host round trip (the 4-byte face count) hides under the other lane's kernels.
     thr_lanes = None
@@ -692,7 +745,7 @@ def main():
                        "frames_per_s": round(world * args.steps * B / dt, 2),
                        "batch_frames": B, "faces_per_frame": K, "gallery": N, "streams": world,
                        "lanes": L, "one_batch_at_a_time": single,
-                       "host_to_host": pcie, "host_to_host_lanes": h2h_lanes,
+                       "host_to_host": pcie, "host_to_host_lanes": h2h_lanes, "jpeg_to_host_lanes": jpeg_lanes,
                        "threshold_mode": thr, "threshold_mode_lanes": thr_lanes, "service_api": svc_line,
                        "gflop_per_frame_detect": round(ctr["det_conv_flops"] / max(1, ctr["frames"]) / 1e9, 2),
                        "gflop_per_face_embed": round(ctr["emb_conv_flops"] / max(1, ctr["faces"]) / 1e9, 3),

@@ -99,11 +99,13 @@ struct frp_handle {
     int64_t g_rows = 0;
     DevBuf g_reserved;               // frp_gallery_reserve: filled by the caller, swapped in by frp_gallery_commit
     // JPEG ingest (frp_upload_jpeg_async): page-locked coefficient staging, device coefficients / tables / sample planes
-    void* jpeg_pin = nullptr;
-    size_t jpeg_pin_cap = 0;
+    // (two staging buffers in turn: the host decodes batch t+1 while the copy of batch t still reads the other one)
+    void* jpeg_pin[2] = {nullptr, nullptr};
+    size_t jpeg_pin_cap[2] = {0, 0};
+    int jpeg_turn = 0;
     DevBuf jpeg_coef, jpeg_planes;
-    hipEvent_t ev_jpeg_h2d = nullptr;     // the copy out of jpeg_pin has finished
-    bool jpeg_h2d_pending = false;
+    hipEvent_t ev_jpeg_h2d[2] = {nullptr, nullptr};     // the copy out of jpeg_pin[i] has finished
+    bool jpeg_h2d_pending[2] = {false, false};
     // exact compat rows (frp_gallery_exact): float64 [g_rows x 512] as enrolled, next to the unit fp16 snapshot
     bool g_exact = false;
     DevBuf gx, gx_q, gx_out;
@@ -1049,8 +1051,10 @@ void frp_destroy(frp_handle* h) {
                      &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    if (h->jpeg_pin) (void)hipHostFree(h->jpeg_pin);
-    if (h->ev_jpeg_h2d) (void)hipEventDestroy(h->ev_jpeg_h2d);
+    for (int i = 0; i < 2; ++i) {
+        if (h->jpeg_pin[i]) (void)hipHostFree(h->jpeg_pin[i]);
+        if (h->ev_jpeg_h2d[i]) (void)hipEventDestroy(h->ev_jpeg_h2d[i]);
+    }
     if (h->h_nfaces) (void)hipHostFree(h->h_nfaces);
     if (h->pin_stage) (void)hipHostFree(h->pin_stage);
     for (void* p : h->pinned) (void)hipHostFree(p);
@@ -1492,18 +1496,20 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
     const size_t ce = jpeg_coef_elems(I);
     // staging: [B] coefficients (int16) then [B][3][64] tables (uint16), 16-byte aligned parts
     const size_t coef_bytes = (size_t)B * ce * 2, q_off = (coef_bytes + 255) & ~(size_t)255, total = q_off + (size_t)B * 3 * 64 * 2;
-    if (h->jpeg_h2d_pending) {                       // the previous batch's copy still reads the page-locked staging
-        HIPCHK(h, hipEventSynchronize(h->ev_jpeg_h2d));
-        h->jpeg_h2d_pending = false;
+    const int turn = h->jpeg_turn;
+    h->jpeg_turn ^= 1;
+    if (h->jpeg_h2d_pending[turn]) {                 // the copy of the batch before the previous one read this staging buffer
+        HIPCHK(h, hipEventSynchronize(h->ev_jpeg_h2d[turn]));
+        h->jpeg_h2d_pending[turn] = false;
     }
-    if (total > h->jpeg_pin_cap) {
-        if (h->jpeg_pin) { (void)hipHostFree(h->jpeg_pin); h->jpeg_pin = nullptr; h->jpeg_pin_cap = 0; }
-        if (hipHostMalloc(&h->jpeg_pin, total, hipHostMallocDefault) != hipSuccess) return fail(h, FRP_ERR_OOM, "hipHostMalloc (JPEG staging) failed");
-        h->jpeg_pin_cap = total;
+    if (total > h->jpeg_pin_cap[turn]) {
+        if (h->jpeg_pin[turn]) { (void)hipHostFree(h->jpeg_pin[turn]); h->jpeg_pin[turn] = nullptr; h->jpeg_pin_cap[turn] = 0; }
+        if (hipHostMalloc(&h->jpeg_pin[turn], total, hipHostMallocDefault) != hipSuccess) return fail(h, FRP_ERR_OOM, "hipHostMalloc (JPEG staging) failed");
+        h->jpeg_pin_cap[turn] = total;
     }
-    if (!h->ev_jpeg_h2d) HIPCHK(h, hipEventCreateWithFlags(&h->ev_jpeg_h2d, hipEventDisableTiming));
-    int16_t* coef = (int16_t*)h->jpeg_pin;
-    uint16_t* qtab = (uint16_t*)((char*)h->jpeg_pin + q_off);
+    if (!h->ev_jpeg_h2d[turn]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_jpeg_h2d[turn], hipEventDisableTiming));
+    int16_t* coef = (int16_t*)h->jpeg_pin[turn];
+    uint16_t* qtab = (uint16_t*)((char*)h->jpeg_pin[turn] + q_off);
     // entropy decoding: one image per task on host threads (the images are independent; within one the bit stream is serial)
     std::vector<int> rcs((size_t)B, FRP_OK);
     std::vector<std::string> errs((size_t)B);
@@ -1552,9 +1558,9 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
         FRPCHK(ensure(h, h->jpeg_planes, (size_t)B * off));
     }
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_next_free, 0));     // the staging frame buffer was the resident one until the last swap
-    HIPCHK(h, hipMemcpyAsync(h->jpeg_coef.p, h->jpeg_pin, total, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipEventRecord(h->ev_jpeg_h2d, h->copy_stream));
-    h->jpeg_h2d_pending = true;
+    HIPCHK(h, hipMemcpyAsync(h->jpeg_coef.p, h->jpeg_pin[turn], total, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_jpeg_h2d[turn], h->copy_stream));
+    h->jpeg_h2d_pending[turn] = true;
     p.coef = (const int16_t*)h->jpeg_coef.p;
     p.qtab = (const uint16_t*)((const char*)h->jpeg_coef.p + q_off);
     p.planes = (uint8_t*)h->jpeg_planes.p;

@@ -27,26 +27,32 @@ const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int kFast = 10;                     // look-ahead bits of the two direct tables
+
 struct HuffTable {
     bool present = false;
     // canonical decoding (T.81 F.2.2.3): per code length the smallest code, the largest code and the value index of the first
     int32_t mincode[17], maxcode[18], valptr[17];
     uint8_t vals[256];
-    // 9-bit look-ahead: (length << 8) | value, 0 = longer than 9 bits
-    uint16_t fast[512];
+    // look-ahead on the next kFast bits: (length << 8) | value, 0 = code longer than kFast bits
+    uint16_t fast[1 << kFast];
+    // AC tables only - code AND magnitude bits inside the look-ahead: (coefficient << 8) | (run << 4) | (code + magnitude
+    // length); 0 = take the general path.  (Most AC symbols of a photographic still are short codes with 1-3 magnitude bits.)
+    int16_t fast_ac[1 << kFast];
 };
 
 bool build_table(HuffTable& t, const uint8_t* counts, const uint8_t* vals, int nvals) {
     int code = 0, k = 0;
     memset(t.fast, 0, sizeof(t.fast));
+    memset(t.fast_ac, 0, sizeof(t.fast_ac));
     for (int len = 1; len <= 16; ++len) {
         t.valptr[len] = k;
         t.mincode[len] = code;
         for (int i = 0; i < counts[len - 1]; ++i, ++k) {
             if (k >= nvals) return false;
-            if (len <= 9) {
-                const int first = code << (9 - len);
-                for (int f = 0; f < (1 << (9 - len)); ++f) t.fast[first + f] = (uint16_t)((len << 8) | vals[k]);
+            if (len <= kFast) {
+                const int first = code << (kFast - len);
+                for (int f = 0; f < (1 << (kFast - len)); ++f) t.fast[first + f] = (uint16_t)((len << 8) | vals[k]);
             }
             ++code;
         }
@@ -56,17 +62,28 @@ bool build_table(HuffTable& t, const uint8_t* counts, const uint8_t* vals, int n
     }
     t.maxcode[17] = 0x7fffffff;
     memcpy(t.vals, vals, (size_t)nvals);
+    for (int i = 0; i < (1 << kFast); ++i) {
+        const uint16_t f = t.fast[i];
+        if (!f) continue;
+        const int len = f >> 8, run = (f >> 4) & 15, mag = f & 15;
+        if (mag == 0 || len + mag > kFast) continue;
+        int v = (i >> (kFast - len - mag)) & ((1 << mag) - 1);          // the magnitude bits behind the code
+        if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;          // T.81 F.2.2.1 EXTEND
+        if (v >= -128 && v <= 127) t.fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + mag);
+    }
     t.present = true;
     return true;
 }
 
+// 64-bit window on the entropy-coded segment, left-aligned: the next bit of the stream is bit 63.  Refilled eight bytes at
+// a time while none of them is 0xFF (no stuffing, no marker), byte by byte around those.
 struct BitReader {
     const uint8_t* p;
     const uint8_t* end;
     uint64_t acc = 0;
     int nbits = 0;
     bool hit_marker = false;      // a marker (other than stuffing) was reached: only zero bits are fed from here on
-    void fill() {
+    void fill_slow() {
         while (nbits <= 56) {
             uint32_t b = 0;
             if (!hit_marker && p < end) {
@@ -84,22 +101,37 @@ struct BitReader {
             nbits += 8;
         }
     }
+    inline void fill() {
+        if (end - p >= 8) {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            const uint64_t inv = ~w;
+            if (!((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull)) {          // no 0xFF among the eight
+                w = __builtin_bswap64(w);
+                const int k = (64 - nbits) >> 3;                                               // whole bytes that fit
+                if (k == 8) acc = w;                                                           // (nbits == 0: the shifts below would be by 64)
+                else acc |= (w >> nbits) & (~0ull << (64 - nbits - 8 * k));
+                p += k;
+                nbits += 8 * k;
+                return;
+            }
+        }
+        fill_slow();
+    }
     inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
     inline void skip(int n) { acc <<= n; nbits -= n; }
+    // callers keep at least 32 bits in the window (a code is at most 16 bits, a magnitude at most 15)
     inline int32_t receive_extend(int s) {
         if (s == 0) return 0;
-        if (nbits < s) fill();
-        const uint32_t v = peek(s);
+        const int32_t v = (int32_t)peek(s);
         skip(s);
-        return v < (1u << (s - 1)) ? (int32_t)v - (1 << s) + 1 : (int32_t)v;
+        return v < (1 << (s - 1)) ? v + (int32_t)((~0u) << s) + 1 : v;
     }
     inline int decode(const HuffTable& t) {
-        if (nbits < 16) fill();
-        const uint16_t f = t.fast[peek(9)];
+        const uint16_t f = t.fast[peek(kFast)];
         if (f) { skip(f >> 8); return f & 0xff; }
-        int32_t code = (int32_t)peek(9);
-        for (int len = 10; len <= 16; ++len) {
-            code = (int32_t)peek(len);
+        for (int len = kFast + 1; len <= 16; ++len) {
+            const int32_t code = (int32_t)peek(len);
             if (t.maxcode[len] >= 0 && code <= t.maxcode[len] && code >= t.mincode[len]) {
                 skip(len);
                 return t.vals[t.valptr[len] + code - t.mincode[len]];
@@ -249,7 +281,6 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
     if (rc != FRP_OK) { if (err) *err = H.err; return rc; }
     const frp_jpeg_info& I = H.info;
     if (!coef || coef_elems < jpeg_coef_elems(I)) { if (err) *err = "coefficient buffer too small"; return FRP_ERR_INVALID; }
-    memset(coef, 0, jpeg_coef_elems(I) * sizeof(int16_t));
     for (int c = 0; c < 3; ++c)
         for (int i = 0; i < 64; ++i) qtab_out[c * 64 + i] = c < I.components ? H.qt[H.comp_tq[c]][i] : 1;
     int16_t* base[3];
@@ -284,11 +315,22 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
                 for (int v = 0; v < I.v_samp[c]; ++v)
                     for (int hh = 0; hh < I.h_samp[c]; ++hh) {
                         int16_t* blk = base[c] + ((size_t)(my * I.v_samp[c] + v) * bx[c] + (mx * I.h_samp[c] + hh)) * 64;
+                        memset(blk, 0, 64 * sizeof(int16_t));          // here, not over the whole buffer up front: the block is about to be written anyway
+                        if (br.nbits < 32) br.fill();
                         const int s = br.decode(dct);
                         if (s < 0 || s > 11) { if (err) *err = "corrupt DC code"; return FRP_ERR_INVALID; }
                         pred[c] += br.receive_extend(s);
                         blk[0] = (int16_t)pred[c];
                         for (int k = 1; k < 64;) {
+                            if (br.nbits < 32) br.fill();
+                            const int fa = act.fast_ac[br.peek(kFast)];
+                            if (fa) {                                  // code + magnitude in one look-up
+                                k += (fa >> 4) & 15;
+                                if (k > 63) { if (err) *err = "corrupt AC run"; return FRP_ERR_INVALID; }
+                                br.skip(fa & 15);
+                                blk[kZigZag[k++]] = (int16_t)(fa >> 8);
+                                continue;
+                            }
                             const int rs = br.decode(act);
                             if (rs < 0) { if (err) *err = "corrupt AC code"; return FRP_ERR_INVALID; }
                             const int r = rs >> 4, sz = rs & 15;
@@ -301,7 +343,6 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
                             blk[kZigZag[k]] = (int16_t)br.receive_extend(sz);
                             ++k;
                         }
-                        if (br.hit_marker && br.nbits < 0) { if (err) *err = "scan data ends early"; return FRP_ERR_INVALID; }
                     }
             }
             if (I.restart_interval) --restart_left;

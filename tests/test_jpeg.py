@@ -65,6 +65,44 @@ def test_generated_camera_size_stills(kw):
         assert np.array_equal(oj.decode_from_coefficients(info, coef, q), _pil_rgb(data))
 
 
+def test_long_codes_large_magnitudes_and_dense_ff_bytes():
+    """quality-100 noise: every block full of large coefficients (magnitudes beyond the direct table's 8 bits, codes beyond its
+    look-ahead, a stuffed 0xFF every few dozen bytes) - the general path of the host decoder, against PIL"""
+    rng = np.random.default_rng(5)
+    img = (rng.integers(0, 2, (34, 50, 3)) * 255).repeat(4, 0).repeat(4, 1).astype(np.uint8) ^ rng.integers(0, 32, (136, 200, 3), dtype=np.uint8)
+    for kw in (dict(quality=100, subsampling=0), dict(quality=100, subsampling=2, optimize=True), dict(quality=100, subsampling=1, restart_marker_blocks=3)):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        data = b.getvalue()
+        assert data.count(b"\xff\x00") > 50
+        info, coef, q = native.jpeg_coefficients(data)
+        assert np.abs(coef).max() > 300
+        assert np.array_equal(oj.decode_from_coefficients(info, coef, q), _pil_rgb(data)), kw
+
+
+def test_damaged_scans_never_crash_the_host_decoder():
+    """bytes of the entropy-coded segment overwritten at random: the call returns coefficients or reports the stream as corrupt;
+    it never reads past the buffer (the buffer handed over ends exactly at the file's last byte)"""
+    good = open(os.path.join(HERE, "golden", "stills", "c420_q90.jpg"), "rb").read() if os.path.exists(os.path.join(HERE, "golden", "stills", "c420_q90.jpg")) else open(STILLS[0], "rb").read()
+    sos = good.find(b"\xff\xda")
+    rng = np.random.default_rng(11)
+    outcomes = set()
+    for trial in range(120):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            i = int(rng.integers(sos + 14, len(bad) - 2))
+            bad[i] = int(rng.integers(0, 256))
+        if trial % 3 == 0:
+            bad = bad[: int(rng.integers(sos + 20, len(bad)))]
+        try:
+            info, coef, q = native.jpeg_coefficients(bytes(bad))
+            outcomes.add("decoded")
+            assert coef.shape[0] > 0
+        except native.FrpError:
+            outcomes.add("refused")
+    assert "decoded" in outcomes
+
+
 def test_files_outside_the_decoders_scope_are_refused_not_half_decoded():
     img = Image.fromarray(np.random.default_rng(1).integers(0, 256, (40, 56, 3), dtype=np.uint8))
     b = io.BytesIO()

@@ -56,6 +56,15 @@ def device_path():
     eng.synchronize()
 
 
+def device_path_pipelined(n=6):
+    """n batches back to back, one wait at the end: the host decodes batch t+1 (second staging buffer) while the copy and the
+    kernels of batch t run - the shape of StagedIngest / lanes in steady state"""
+    for _ in range(n):
+        eng.upload_jpeg_async(jpegs)
+        eng.swap_frames()
+    eng.synchronize()
+
+
 for name, fn in (("PIL on one host thread + upload", host_path), ("PIL on 16 host threads + upload", host_path_threads),
                  ("frp_upload_jpeg_async (host entropy decode + device pixels)", device_path)):
     fn()
@@ -65,3 +74,16 @@ for name, fn in (("PIL on one host thread + upload", host_path), ("PIL on 16 hos
         fn()
         best = min(best, time.perf_counter() - t0)
     print(f"  {name:62s} {best * 1e3:8.1f} ms per batch  {B / best:8.0f} frames/s")
+device_path_pipelined()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    device_path_pipelined(6)
+    best = min(best, (time.perf_counter() - t0) / 6)
+print(f"  {'frp_upload_jpeg_async, 6 batches in a row, one wait at the end':62s} {best * 1e3:8.1f} ms per batch  {B / best:8.0f} frames/s")
+import threading
+t0 = time.perf_counter()
+ths = [threading.Thread(target=lambda lo=lo: [native.jpeg_coefficients(j) for j in jpegs[lo::16]]) for lo in range(16)]
+[t.start() for t in ths]
+[t.join() for t in ths]
+print(f"  {'(host entropy decode alone, 16 threads, through ctypes)':62s} {(time.perf_counter() - t0) * 1e3:8.1f} ms per batch")
