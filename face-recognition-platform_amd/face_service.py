@@ -581,6 +581,9 @@ class FaceService:
                 if nxt is not None:
                     eng.upload_frames_async(nxt)                       # copy stream: under this batch's kernels
                     staged["key"] = id(nxt)
+                idle = getattr(take_next, "idle", None)
+                if idle is not None:
+                    idle()                                             # the PREVIOUS batch's result dicts, under this batch's kernels
                 out = eng.fetch_results()                              # waits for the pass
             else:
                 out = eng.process_frames(frames_bgr, max_faces=max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)
@@ -591,47 +594,52 @@ class FaceService:
                 Q = np.concatenate([out["emb"][b, :int(c)] for b, c in enumerate(out["counts"])])
                 names = G.names()
                 all_d = cos_to_distance(eng.match_scores(Q)[:, G.rows_of(names)])
-        # One pass of array arithmetic for the whole batch (distance, bucket, threshold), ONE tolist() per field; the per-face
-        # work left is building the dict (the reference builds N of them per face, camera.py:243-259).
-        counts = np.asarray(out["counts"], dtype=np.int64)
-        K = out["match_idx"].shape[1]
-        live = np.arange(K)[None, :] < counts[:, None]                    # [B, K]: slots that hold a face
-        rows = out["match_idx"][live].astype(np.int64)
-        hit = rows >= 0
-        cos = out["match_cos"][live].astype(np.float64)
-        dist = cos_to_distance(cos)
-        conf = np.where(dist < 0.4, "high", np.where(dist < 0.6, "medium", "low"))         # confidence_level, vectorised
-        is_match = hit & (dist <= tol)
-        boxes, kps, scores = out["boxes"][live].tolist(), out["kps"][live].tolist(), out["scores"][live].tolist()
-        emb = out["emb"][live]                                            # [n, 512]: one gather, rows handed out as views
-        rows_l, hit_l, cos_l, dist_l, conf_l, match_l = rows.tolist(), hit.tolist(), cos.tolist(), dist.tolist(), conf.tolist(), is_match.tolist()
-        result = []
-        f_idx = 0
-        for c in counts.tolist():
-            faces = []
-            for _ in range(c):
-                i = f_idx
-                h_ = hit_l[i]
-                face = {"bbox": boxes[i], "kps": kps[i], "score": scores[i], "embedding": emb[i],
-                        "target": row_names.get(rows_l[i]) if h_ else None,
-                        "distance": dist_l[i] if h_ else None, "cosine": cos_l[i] if h_ else None,
-                        "confidence": conf_l[i] if h_ else None, "match": match_l[i]}
-                if all_matches:
-                    hits = []
-                    if all_d is not None:
-                        dd = all_d[i]
-                        order = np.argsort(dd, kind="stable")          # compare_faces sorts ascending (:432)
-                        hits = [{"target": names[j], "distance": float(dd[j]), "confidence": confidence_level(float(dd[j]))}
-                                for j in order if dd[j] <= tol]
-                    face["matches"] = hits
-                faces.append(face)
-                f_idx += 1
-            result.append(faces)
-        n_total = f_idx
-        with self._metrics_lock:
-            self._metrics["total_encodings"] += n_total
-            self._metrics["total_comparisons"] += n_total * n_gallery
-        return result
+        def build():
+            # One pass of array arithmetic for the whole batch (distance, bucket, threshold), ONE tolist() per field; the per-face
+            # work left is building the dict (the reference builds N of them per face, camera.py:243-259).
+            counts = np.asarray(out["counts"], dtype=np.int64)
+            K = out["match_idx"].shape[1]
+            live = np.arange(K)[None, :] < counts[:, None]                    # [B, K]: slots that hold a face
+            rows = out["match_idx"][live].astype(np.int64)
+            hit = rows >= 0
+            cos = out["match_cos"][live].astype(np.float64)
+            dist = cos_to_distance(cos)
+            conf = np.where(dist < 0.4, "high", np.where(dist < 0.6, "medium", "low"))         # confidence_level, vectorised
+            is_match = hit & (dist <= tol)
+            boxes, kps, scores = out["boxes"][live].tolist(), out["kps"][live].tolist(), out["scores"][live].tolist()
+            emb = out["emb"][live]                                            # [n, 512]: one gather, rows handed out as views
+            rows_l, hit_l, cos_l, dist_l, conf_l, match_l = rows.tolist(), hit.tolist(), cos.tolist(), dist.tolist(), conf.tolist(), is_match.tolist()
+            result = []
+            f_idx = 0
+            for c in counts.tolist():
+                faces = []
+                for _ in range(c):
+                    i = f_idx
+                    h_ = hit_l[i]
+                    face = {"bbox": boxes[i], "kps": kps[i], "score": scores[i], "embedding": emb[i],
+                            "target": row_names.get(rows_l[i]) if h_ else None,
+                            "distance": dist_l[i] if h_ else None, "cosine": cos_l[i] if h_ else None,
+                            "confidence": conf_l[i] if h_ else None, "match": match_l[i]}
+                    if all_matches:
+                        hits = []
+                        if all_d is not None:
+                            dd = all_d[i]
+                            order = np.argsort(dd, kind="stable")          # compare_faces sorts ascending (:432)
+                            hits = [{"target": names[j], "distance": float(dd[j]), "confidence": confidence_level(float(dd[j]))}
+                                    for j in order if dd[j] <= tol]
+                        face["matches"] = hits
+                    faces.append(face)
+                    f_idx += 1
+                result.append(faces)
+            n_total = f_idx
+            with self._metrics_lock:
+                self._metrics["total_encodings"] += n_total
+                self._metrics["total_comparisons"] += n_total * n_gallery
+            return result
+
+        # process_stream: the dicts of this batch are built by the lane's thread while its NEXT batch is on the device
+        # (lanes.Deferred); everything they need was taken above, under the guard.
+        return lanes.Deferred(build) if overlapped else build()
 
     def process_stream(self, batches, max_faces: int = 10, threshold: Optional[float] = None,
                        det_thresh: Optional[float] = None, all_matches: bool = False):

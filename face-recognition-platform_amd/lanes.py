@@ -25,6 +25,17 @@ import numpy as np
 from . import native
 
 
+class Deferred:
+    """What a prefetch-mode worker may return instead of a result: `finish()` builds the result from what the device handed
+    back (host-only work: no device call, no lock of the pipeline).  run_ordered runs it where the lane's thread would
+    otherwise sit waiting - inside the worker's NEXT call, after that call has put its batch on the device
+    (`take_next.idle()`), or at once when the worker has no next item in hand."""
+    __slots__ = ("finish",)
+
+    def __init__(self, finish: Callable[[], Any]):
+        self.finish = finish
+
+
 def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], prefetch: bool = False) -> Iterator[Any]:
     """The one in-order, bounded-look-ahead pipeline behind Lanes.run and FaceService.process_stream: `workers[i]` (one
     host thread each) turn items of `batches` into results; results are yielded in submission order; at most
@@ -41,7 +52,12 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
     it only takes an item the feeder has already delivered - claims the item this worker will get NEXT (or None:
     nothing ready, source dry) so that the worker can start moving it to the device while the current item is being
     processed (FaceService.process_stream: the upload of batch t+1 overlaps the kernels of batch t on the same lane).
-    A worker may therefore call it while holding locks of its own (the gallery's shared lock)."""
+    A worker may therefore call it while holding locks of its own (the gallery's shared lock).
+    A prefetch-mode worker may return a `Deferred`: its `finish()` (host-side result building) then runs on the same thread
+    under the device work of that worker's next item - the worker calls `take_next.idle()` once its next batch is on the
+    device - or immediately if the worker has not claimed a next item (so a result is never held back by a dry source).
+    With deferral a lane holds three items (one being finished, one on the device, one staged), so the look-ahead bound
+    is 3 x len(workers) in prefetch mode, 2 x len(workers) otherwise."""
     it = iter(batches)
     n = len(workers)
     if n < 1:
@@ -49,10 +65,12 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
     cv = threading.Condition()
     st = {"next": 0, "yielded": 0, "fed": 0, "done": {}, "ready": [], "src_done": False, "stopped": False, "error": None}
 
+    depth = (3 if prefetch else 2) * n
+
     def feeder() -> None:
         while True:
             with cv:
-                while st["fed"] - st["yielded"] >= 2 * n and not st["stopped"] and st["error"] is None:
+                while st["fed"] - st["yielded"] >= depth and not st["stopped"] and st["error"] is None:
                     cv.wait()
                 if st["stopped"] or st["error"] is not None:
                     return
@@ -86,6 +104,19 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
 
     def loop(fn: Callable[..., Any]) -> None:
         ahead = None                     # the item this worker claimed early (prefetch)
+        pending = None                   # (index, Deferred) of this worker's previous item
+
+        def publish(t: int, out: Any) -> None:
+            with cv:
+                st["done"][t] = out
+                cv.notify_all()
+
+        def idle() -> None:
+            nonlocal pending
+            if pending is not None:
+                (t_prev, d), pending = pending, None
+                publish(t_prev, d.finish())
+
         while True:
             if ahead is not None:
                 (t, item), ahead = ahead, None
@@ -103,7 +134,14 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
                             with cv:
                                 ahead = claim(False)
                         return None if ahead is None else ahead[1]
+                    take_next.idle = idle
                     out = fn(item, take_next)
+                    idle()                                   # a worker that never called it: before this item's own result
+                    if isinstance(out, Deferred):
+                        if ahead is not None:
+                            pending = (t, out)               # finished inside the call for `ahead`
+                            continue
+                        out = out.finish()
                 else:
                     out = fn(item)
             except BaseException as ex:
@@ -111,9 +149,7 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
                     st["error"] = ex
                     cv.notify_all()
                 return
-            with cv:
-                st["done"][t] = out
-                cv.notify_all()
+            publish(t, out)
 
     feed = threading.Thread(target=feeder, daemon=True)
     threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]

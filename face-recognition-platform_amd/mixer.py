@@ -77,8 +77,8 @@ class StreamMixer:
 
     streams      : {stream id: capture-like object}; ids are served round-robin in the order given
     buffers      : page-locked [batch, H, W, 3] u8 arrays used in rotation (FaceService.frame_buffer /
-                   Engine.host_frames); at least 2 x lanes + 2 of them, so that a buffer is not rewritten while its batch
-                   is still in flight (run_ordered takes 2 x lanes batches ahead).  Plain numpy arrays work too (tests).
+                   Engine.host_frames); at least 3 x lanes + 2 of them, so that a buffer is not rewritten while its batch
+                   is still in flight (process_stream's pipeline takes 3 x lanes batches ahead).  Plain numpy arrays work too (tests).
     frame_skip   : reads per kept frame, the last one is kept (camera.py:204-213); a failed read ends the stream's turn
                    (after ONE reopen attempt for a closed capture, camera.py:185-200)
     fps_limit    : {stream id: fps} or a number for all: minimum spacing of kept frames (camera.py:216-221)

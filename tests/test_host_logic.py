@@ -550,6 +550,63 @@ def test_abandoned_stream_with_full_look_ahead_does_not_deadlock(monkeypatch):
         next(lanes_mod.run_ordered([1], []))
 
 
+def test_run_ordered_deferred_results_are_finished_under_the_next_item_or_at_once():
+    """lanes.Deferred (FaceService.process_stream builds a batch's result dicts while the lane's next batch is on the device):
+    finish() runs on the worker's own thread - inside its next call, where that call invokes take_next.idle(), when a next item
+    had been claimed; immediately when none had - every result arrives exactly once, in order, also when the source is
+    slower than the workers (nothing claimed ahead: nothing may be held back) and when a worker never calls idle()."""
+    import itertools
+    import threading
+    import time
+    from frp_amd import lanes as lanes_mod
+
+    for slow_source, calls_idle in ((False, True), (True, True), (False, False)):
+        log = []
+        lock = threading.Lock()
+
+        def src(n):
+            for t in range(n):
+                if slow_source:
+                    time.sleep(0.004)
+                yield t
+
+        def make(w):
+            def fn(item, take_next):
+                time.sleep(0.001)
+                nxt = take_next()
+                if calls_idle:
+                    take_next.idle()
+                me = threading.get_ident()
+
+                def finish():
+                    assert threading.get_ident() == me                 # the lane's own thread
+                    with lock:
+                        log.append(("finish", item, nxt))
+                    return item * 10
+                return lanes_mod.Deferred(finish)
+            return fn
+
+        outs = list(lanes_mod.run_ordered(src(30), [make(0), make(1)], prefetch=True))
+        assert outs == [t * 10 for t in range(30)], (slow_source, calls_idle)
+        assert sorted(x[1] for x in log) == list(range(30))
+        if slow_source:
+            assert any(x[2] is None for x in log)                      # finished at once: no next item was in hand
+
+    # a failing finish() surfaces in the consumer like any worker error
+    def bad(item, take_next):
+        take_next()
+        def finish():
+            raise RuntimeError("boom")
+        return lanes_mod.Deferred(finish)
+    with pytest.raises(RuntimeError, match="boom"):
+        list(lanes_mod.run_ordered(iter(range(5)), [bad, bad], prefetch=True))
+
+    # abandoning the generator with deferred results pending does not hang
+    g = lanes_mod.run_ordered(itertools.count(), [make(0), make(1)], prefetch=True)
+    assert next(g) == 0
+    g.close()
+
+
 def test_run_ordered_prefetch_hands_every_item_to_exactly_one_worker_in_order():
     """prefetch mode (FaceService.process_stream: the next batch's upload overlaps the running one): a worker may claim
     its NEXT item while it works; every item is processed once, by the worker that claimed it, results stay in
