@@ -35,6 +35,7 @@ import numpy as np
 
 from . import lanes, native
 from .gallery import Gallery
+from .mjpeg import JpegBatch
 
 logger = logging.getLogger(__name__)
 
@@ -569,7 +570,7 @@ class FaceService:
         if overlapped:
             key = id(frames_bgr)
             if staged.pop("key", None) != key:                         # not staged by the previous call: stage it now
-                eng.upload_frames_async(frames_bgr)
+                self._stage_on(eng, frames_bgr)
             eng.swap_frames()
         with guard:
             have_gallery = len(G) > 0
@@ -579,13 +580,21 @@ class FaceService:
                 eng.process_resident(max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)       # asynchronous
                 nxt = take_next()
                 if nxt is not None:
-                    eng.upload_frames_async(nxt)                       # copy stream: under this batch's kernels
+                    self._stage_on(eng, nxt)                           # copy stream: under this batch's kernels
                     staged["key"] = id(nxt)
                 idle = getattr(take_next, "idle", None)
                 if idle is not None:
                     idle()                                             # the PREVIOUS batch's result dicts, under this batch's kernels
                 out = eng.fetch_results()                              # waits for the pass
+            elif isinstance(frames_bgr, JpegBatch) and hasattr(eng, "upload_jpeg_async"):
+                with eng.sequence():
+                    self._stage_on(eng, frames_bgr)
+                    eng.swap_frames()
+                    eng.process_resident(max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)
+                    out = eng.fetch_results()
             else:
+                if isinstance(frames_bgr, JpegBatch):
+                    frames_bgr = frames_bgr.decode()                   # an engine without the device decoder (tests' FakeEngine)
                 out = eng.process_frames(frames_bgr, max_faces=max_faces, det_thresh=dt, nms_iou=NMS_IOU, flags=fl)
             n_gallery = len(G)
             row_names = {int(r): G.name_of_row(int(r)) for r in np.unique(out["match_idx"]) if r >= 0}
@@ -640,6 +649,20 @@ class FaceService:
         # process_stream: the dicts of this batch are built by the lane's thread while its NEXT batch is on the device
         # (lanes.Deferred); everything they need was taken above, under the guard.
         return lanes.Deferred(build) if overlapped else build()
+
+    @staticmethod
+    def _stage_on(eng, batch) -> None:
+        """start moving a batch into the lane's staging frame buffer: pixel arrays by DMA, encoded batches (mjpeg.JpegBatch)
+        through the engine's JPEG path - bit streams decoded here on host threads, pixels produced on the copy stream -
+        unless the device decoder does not cover the batch (progressive frames, mixed sampling): then PIL decodes it"""
+        if isinstance(batch, JpegBatch):
+            from . import ingest
+            jp = ingest.device_jpeg_batch(batch, len(batch), batch.hw)
+            if jp is not None:
+                eng.upload_jpeg_async(jp)
+                return
+            batch = batch.decode()
+        eng.upload_frames_async(batch)
 
     def process_stream(self, batches, max_faces: int = 10, threshold: Optional[float] = None,
                        det_thresh: Optional[float] = None, all_matches: bool = False):

@@ -82,13 +82,17 @@ class StreamMixer:
     frame_skip   : reads per kept frame, the last one is kept (camera.py:204-213); a failed read ends the stream's turn
                    (after ONE reopen attempt for a closed capture, camera.py:185-200)
     fps_limit    : {stream id: fps} or a number for all: minimum spacing of kept frames (camera.py:216-221)
+    encoded      : the streams deliver ENCODED frames (mjpeg.MjpegCapture: JPEG bytes) and the batches stay encoded - the mixer
+                   yields (mjpeg.JpegBatch, meta) and the engine decodes a batch on the way to the device
+                   (frp_upload_jpeg_async); `buffers` then only gives the batch geometry (their [1:3] shape) and may be plain
+                   arrays.  A slot whose stream has ended repeats another slot's frame (its meta stays None: the result is dropped).
     Yields (buffer, meta) with meta[i] = (stream id, index of the kept frame in that stream) or None for a slot left
     empty (zeroed) because its stream had ended; stops when no stream delivers any more.
     """
 
     def __init__(self, streams: Dict[Any, Any], batch: int, buffers: Sequence[np.ndarray], frame_skip: int = 1,
                  fps_limit=None, decode_workers: int = 4, clock: Callable[[], float] = time.time,
-                 sleep: Callable[[float], None] = time.sleep):
+                 sleep: Callable[[float], None] = time.sleep, encoded: bool = False):
         if not streams or batch < 1 or not buffers:
             raise ValueError("need at least one stream, one batch slot and one buffer")
         for b in buffers:
@@ -107,6 +111,7 @@ class StreamMixer:
         self._pool = ThreadPoolExecutor(max_workers=max(1, decode_workers))
         self._lock = threading.Lock()
         self.dropped_reads = 0
+        self.encoded = bool(encoded)
 
     def close(self) -> None:
         self._pool.shutdown(wait=True)
@@ -147,7 +152,31 @@ class StreamMixer:
         self._kept[sid] += 1
         return idx, frame
 
+    def _iter_encoded(self):
+        from .mjpeg import JpegBatch
+        n = len(self.order)
+        hw = self.buffers[0].shape[1:3]
+        while True:
+            meta: List[Optional[Tuple[Any, int]]] = [None] * self.batch
+            frames: List[Any] = [None] * self.batch
+            for slot in range(self.batch):
+                got = self._next_kept(self.order[slot % n])
+                if got is None:
+                    continue
+                idx, frame = got
+                if not isinstance(frame, (bytes, bytearray)):
+                    raise ValueError("StreamMixer(encoded=True): the streams must deliver encoded frames (bytes)")
+                meta[slot] = (self.order[slot % n], idx)
+                frames[slot] = frame
+            filler = next((f for f in frames if f is not None), None)
+            if filler is None:
+                return
+            yield JpegBatch([f if f is not None else filler for f in frames], hw), meta
+
     def __iter__(self) -> Iterator[Tuple[np.ndarray, List[Optional[Tuple[Any, int]]]]]:
+        if self.encoded:
+            yield from self._iter_encoded()
+            return
         n = len(self.order)
         bi = 0
         while True:
