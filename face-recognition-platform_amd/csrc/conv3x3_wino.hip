@@ -61,12 +61,12 @@ __device__ __forceinline__ half8 wsub(half8 a, half8 b) {
 // once - 64 + 64 registers - spilled, and a spilled epilogue took 19 us per tile).  The residual of unit u + 1 is requested
 // before unit u is finished.  Specialised at compile time on (full tile, activation, residual) like the direct kernels.
 // residual of one (cout block c, parity) unit in the store layout, from clamped - always valid - addresses
-template <int PB>
+template <int PB, bool OVER = false>
 __device__ __forceinline__ void wino_load_res(const ConvParams& p, uint4 (&r)[PB][1][2], int c, int par, int m0, int c0, int pair0,
-                                              int crow0, int fr, int fh) {
+                                              int crow0, int fr, int fh, int m_over = 0) {
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
-        const int mraw = m0 + (pair0 + b * 32 + fr) * 2 + par;
+        const int mraw = OVER ? (m_over >= 0 ? m_over + par : p.M) : m0 + (pair0 + b * 32 + fr) * 2 + par;
         int m = mraw < p.M ? mraw : 0;
 #ifdef FRP_LAB   // dbg code 8 (wrong results by design): every tile reads the residual of the first 256 pixels - an L2-resident
         if (((p.dbg >> 1) & 15) == 8) m &= 255;                  // 64 KiB: what the epilogue would cost if the residual came from L2
@@ -84,13 +84,14 @@ __device__ __forceinline__ void wino_load_res(const ConvParams& p, uint4 (&r)[PB
 // not have cost registers - the request written into the raw-fragment registers, dead in a tile's last sub-step; the last
 // channel block peeled into its own copy of the body, `last_cb` a literal -: 25 / 26 spilled registers instead of 12, some of
 // them in the per-tile head, embedder 8.02 vs 7.83 ms in the same-box A/B.  The ~2 us stay exposed: 0.26 ms of a step.)
-template <int PB, bool FULL, int ACT, int RES>
+template <int PB, bool FULL, int ACT, int RES, bool OVER = false>
 __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16 (&acc)[4][PB][2],
                                                    const float* lds_bias, const float* lds_slope, int m0, int c0, int pair0, int crow0,
-                                                   int fr, int fh, int HoWo, float inv_howo, float inv_wo) {
+                                                   int fr, int fh, int HoWo, float inv_howo, float inv_wo, int m_over = 0) {
+    // OVER / m_over (2-D tiles): pixel index of the lane's pair (its even pixel), -1 for a pair that does not exist
     const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
     uint4 rr[2][PB][1][2];
-    auto load_res = [&](int c, int par, uint4 (&r)[PB][1][2]) { wino_load_res<PB>(p, r, c, par, m0, c0, pair0, crow0, fr, fh); };
+    auto load_res = [&](int c, int par, uint4 (&r)[PB][1][2]) { wino_load_res<PB, OVER>(p, r, c, par, m0, c0, pair0, crow0, fr, fh, m_over); };
     if (has_res) load_res(0, 0, rr[0]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -102,8 +103,8 @@ __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 y[b][0][e] = par ? (acc[1][b][c][e] - acc[2][b][c][e]) - acc[3][b][c][e] : (acc[0][b][c][e] + acc[1][b][c][e]) + acc[2][b][c][e];
-        conv_epilogue_body<PB, 1, WN_TC_, FULL, ACT, RES>(p, y, rr[u & 1], lds_bias, lds_slope, m0, c0, pair0, crow0 + c * 32, fr, fh, HoWo,
-                                                          inv_howo, inv_wo, 2, par);
+        conv_epilogue_body<PB, 1, WN_TC_, FULL, ACT, RES, OVER>(p, y, rr[u & 1], lds_bias, lds_slope, m0, c0, pair0, crow0 + c * 32, fr, fh, HoWo,
+                                                                inv_howo, inv_wo, 2, par, m_over);
     }
 }
 
@@ -588,7 +589,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     ConvParams p = p_in;
     constexpr int TP = WN_TP, TC = WN_TC;
     constexpr int AHEAD = (VAR & 16) ? 2 : 3;  // sub-steps the weight ring runs ahead (lab: VAR & 16 = two)
-    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+    // VAR & 32: 2-D tiles for maps wider than the super-patch allows (the detector's): a tile = 8 rows x 30 columns of one image.
+    // Its halo'd patch is 10 x 32 pixels = the 320 LDS rows of the flattened form, and with 16 pairs per tile row (15 real + one that
+    // never exists) every consumer-side address is the flattened formula at W = 32: the kernel runs on a 32-wide virtual strip.
+    // What differs: the source side of the patch DMA (a piece = half a patch row), the validity masks, the epilogue's pixel index.
+    constexpr bool T2D = (VAR & 32) != 0;
+    constexpr int T2H = 8, T2W = 30;
+    const int t2x = T2D ? (p.W + T2W - 1) / T2W : 1, t2y = T2D ? (p.H + T2H - 1) / T2H : 1;      // tiles per image row / column
+    if (!T2D && p.n_dev) {                     // image count known on the device only (threshold mode)
         int n = *p.n_dev;
         n = n < 0 ? 0 : (n > p.N ? p.N : n);
         p.M = n * p.Ho * p.Wo;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     if (t0 >= t1) return;
     const int cpt = p.Cin >> 6;                // 64-channel blocks
     const int cin2 = p.Cin * 2;                // bytes per pixel
-    const int HALF = wino_half_rows(p.W);      // 160 (launcher: 40 row groups of 8 rows per patch)
+    const int HALF = T2D ? 160 : wino_half_rows(p.W);      // 160 (launcher: 40 row groups of 8 rows per patch)
     const int XSLOT = 2 * HALF * 128;
     const int OFF_W = 2 * XSLOT;
     const int OFF_Z = OFF_W + WN_NSW * WN_WSLOT;
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     // 16-byte position lane % 8 holding logical chunk pos ^ ((row >> 1) & 7) (source-side swizzle)
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
-    const int xlane = (2 * lrow - p.W - 1) * cin2 + lchunk * 16;
+    const int xlane = (T2D ? 2 * lrow : 2 * lrow - p.W - 1) * cin2 + lchunk * 16;     // (2-D: the patch origin is part of the tile's base)
     // patch piece j of this wave = LDS row group wave + 8 j; rows below HALF hold the even pixel offsets r = 2 row, the
     // others r = 2 (row - HALF) + 1 of the super-patch; its scalar source offset (added to the per-lane part per piece)
     // VAR & 8 (lab): only waves 0-3 - the older wave of every SIMD, which reaches the barrier ~170 cycles before its partner -
@@ -642,6 +650,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
 #pragma unroll
     for (int j = 0; j < XPW; ++j) {
         const int row0 = (wave + NDW * j) * 8;
+        if constexpr (T2D) {                   // row group g: patch row py = g' / 2, its pair columns 8 (g' & 1) .. + 7, g' = g mod 20; parity g / 20
+            const int g = wave + NDW * j, gg = g < 20 ? g : g - 20;
+            sxo[j] = ((gg >> 1) * p.W + ((gg & 1) << 4) + (g < 20 ? 0 : 1)) * cin2;
+        } else
         sxo[j] = (row0 < HALF ? 2 * row0 : 2 * (row0 - HALF) + 1) * cin2;
     }
     constexpr int DEAD = (int)0x80000000;
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     // byte address of its kk = 0 fragment (kk flips address bits 5..6); lanes whose tap falls off the image (or whose pair
     // does not exist) read a 256-byte zero block at the bank offset their real address would have had
     auto raw_addr = [&](unsigned mask, int kh, int i, int xslot) -> unsigned {
-        const int row = pair0 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+        const int row = pair0 + fr_e + (i >> 1) + kh * (T2D ? 16 : (p.W >> 1)) + (i & 1) * HALF;
         const int a_ = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
         const bool rowok = (mask & 1u) && (kh == 0 ? (mask & 2u) : kh == 2 ? (mask & 4u) : true);
         const bool ok = rowok && (i == 0 ? (mask & 8u) : i == 3 ? (mask & 16u) : true);
@@ -694,14 +706,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     };
 
     struct Tile { int m0b; int wbase; unsigned vmask; };
+    int mt_cur = 0, mt_nxt = 0;                // (2-D tiles) pixel index of the tile's first pixel
     // vmask: validity bits of this lane's pair: 1 pair exists, 2 row above inside, 4 row below inside, 8 left neighbour (d0)
     // inside, 16 right neighbour (d3) inside
     auto make_tile = [&](int tile, Tile& d) {
         if (tile >= t1) { d.m0b = DEAD; d.wbase = DEAD; d.vmask = 0; return; }
         const int pt = tile / p.n_ctiles;
         const int ct_ = tile - pt * p.n_ctiles;
-        d.m0b = pt * TP * cin2;
         d.wbase = ct_ * cpt * 12 * WN_WSLOT;
+        if constexpr (T2D) {
+            const int per = t2x * t2y;
+            const int n = pt / per, r = pt - n * per;
+            const int ty = r / t2x, tx = r - ty * t2x;
+            const int y0 = ty * T2H, x0 = tx * T2W;
+            mt_nxt = (n * p.H + y0) * p.W + x0;
+            d.m0b = (mt_nxt - p.W - 1) * cin2;                        // the patch starts one row above, one column left of the tile
+            const int pl = pair0 + fr_e, y = y0 + (pl >> 4), x = x0 + 2 * (pl & 15);
+            unsigned mask = 0;
+            if ((pl & 15) < 15 && y < p.H && x < p.W)
+                mask = 1u | (y > 0 ? 2u : 0u) | (y < p.H - 1 ? 4u : 0u) | (x > 0 ? 8u : 0u) | (x + 2 < p.W ? 16u : 0u);
+            d.vmask = mask;
+            return;
+        }
+        d.m0b = pt * TP * cin2;
         const int m = pt * TP + 2 * (pair0 + fr_e);
         unsigned mask = 0;
         if (m < p.M) {
@@ -720,6 +747,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
     Tile cur, nt;
     make_tile(t0, cur);
+    if constexpr (T2D) mt_cur = mt_nxt;
     {
         const unsigned xb0 = (unsigned)(cur.m0b + xlane);
         if (dma_wave) {
@@ -776,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned mask = cur.vmask;
-                const int row = pair0 + fr_e + (i >> 1) + kh * (p.W >> 1) + (i & 1) * HALF;
+                const int row = pair0 + fr_e + (i >> 1) + kh * (T2D ? 16 : (p.W >> 1)) + (i & 1) * HALF;
                 const int a_ = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
                 const bool rowok = (mask & 1u) && (kh == 0 ? (mask & 2u) : kh == 2 ? (mask & 4u) : true);
                 const bool ok = rowok && (i == 0 ? (mask & 8u) : i == 3 ? (mask & 16u) : true);
@@ -910,8 +938,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         {
             floatx16 (&acc4)[4][1][2] = *reinterpret_cast<floatx16 (*)[4][1][2]>(&acc);
 #define WN_EPI(FULL_, ACT_, RES_) \
-    wino_tile_epilogue<1, FULL_, ACT_, RES_>(p, acc4, lds_bias, lds_slope, m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo)
-            const bool full = m0 + TP <= p.M && c0 + TC <= p.Cout;
+    wino_tile_epilogue<1, FULL_, ACT_, RES_, T2D>(p, acc4, lds_bias, lds_slope, m0, c0, pair0, crow0, fr_e, fh_e, HoWo, inv_howo, inv_wo, m_over)
+            int m_over = 0;
+            if constexpr (T2D) {               // every 2-D tile has pairs that do not exist (the 16th of a tile row): masked stores throughout
+                const int pl = pair0 + fr_e;
+                m_over = (cur.vmask & 1u) ? mt_cur + (pl >> 4) * p.W + 2 * (pl & 15) : -1;
+            }
+            const bool full = !T2D && m0 + TP <= p.M && c0 + TC <= p.Cout;
+            if (T2D && c0 + TC <= p.Cout) {
+                if (p.act == FRP_ACT_PRELU) { if (has_res) WN_EPI(false, FRP_ACT_PRELU, 1); else WN_EPI(false, FRP_ACT_PRELU, 0); }
+                else if (p.act == FRP_ACT_RELU) { if (has_res) WN_EPI(false, FRP_ACT_RELU, 1); else WN_EPI(false, FRP_ACT_RELU, 0); }
+                else { if (has_res) WN_EPI(false, FRP_ACT_NONE, 1); else WN_EPI(false, FRP_ACT_NONE, 0); }
+            } else
             if (!full) WN_EPI(false, -1, -1);
             else if (p.act == FRP_ACT_PRELU) { if (has_res) WN_EPI(true, FRP_ACT_PRELU, 1); else WN_EPI(true, FRP_ACT_PRELU, 0); }
             else if (p.act == FRP_ACT_RELU) { if (has_res) WN_EPI(true, FRP_ACT_RELU, 1); else WN_EPI(true, FRP_ACT_RELU, 0); }
@@ -919,6 +957,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
 #undef WN_EPI
         }
         cur = nt;
+        if constexpr (T2D) mt_cur = mt_nxt;
         if (ct + tstep < t1) first_operands(cur, xs);       // (its patch and stage 0 landed before this tile's last barrier)
         if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 5); }
     }
@@ -933,16 +972,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     } else stamp(p.stamps, 6);
 }
 
+// 2-D tiles (8 rows x 30 columns of one image; conv3x3_wino2_kernel<32>) for maps wider than the flattened tiles cover: where they pay.
+// A tile carries 240 real pixels in 256 pixel slots and the edge tiles of a map carry less; against that stand the kernel's x1.12
+// (128 channels: 24 sub-steps per tile, a third of a tile is prologue + epilogue) and x1.2 (256 channels and more) over the direct
+// kernel.  Measured (tools/wino_probe.py, 32 frames): 136 x 240 x 128: x1.08-1.11, 68 x 120 x 256: x1.09, 68 x 120 x 128: x1.00,
+// 34 x 60 x 256: x0.98.  Fewer than two rounds of tiles: the direct family (its quarter tiles fill the chip better).
+bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu) {
+    if ((W & 1) || W <= 30 || Cin < 128 || (Cin & 63)) return false;
+    const long ty = (H + 7) / 8, tx = (W + 29) / 30;
+    const long tiles = (long)N * ty * tx * ((Cout + WN_TC - 1) / WN_TC);
+    if (tiles < 2L * (n_cu > 0 ? n_cu : 256)) return false;
+    const double slots = (double)(ty * 8) * (double)(tx * 32), real = (double)H * W;
+    return (Cin >= 256 ? 1.2 : 1.12) * real / slots >= 1.03;
+}
+static bool wino_2d_pays(const ConvParams& p) {
+    return !p.n_dev && (long)p.N * p.H * p.W == (long)p.M && conv3x3_wino_wide_pays(p.N, p.H, p.W, p.Cin, p.Cout, p.n_cu);
+}
+
+// which form of the kernel a launch takes: 0 none, 1 flattened tiles (maps up to 30 wide), 2 the 2-D tiles
+static int wino_form(const ConvParams& p) {
+    if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return 0;
+    if (p.Ho != p.H || p.Wo != p.W) return 0;
+    if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return 0;
+#ifdef FRP_LAB    // dbg bit 256 (conv2d / conv_bench flags bit 19): the 2-D tiles whatever the shape; dbg bit 64: the first generation's
+    if ((p.dbg & 256) && !p.n_dev && conv3x3_wino_lab_shape_ok(p.W, p.Cin, p.KS, p.stride)) return 2;      // row-patch form for wide maps
+    if ((p.dbg & 64) && conv3x3_wino_lab_shape_ok(p.W, p.Cin, p.KS, p.stride)) return 1;                   // (slower than the direct kernel)
+#endif
+    if (!p.wino_wide_only && conv3x3_wino_shape_ok(p.W, p.Cin, p.KS, p.stride)) return 1;
+    return wino_2d_pays(p) ? 2 : 0;
+}
+
 // Shapes the Winograd kernel covers; `p` carries the derived fields of launch_conv().
 bool conv3x3_wino_eligible(const ConvParams& p) {
-    if (p.KS != 3 || p.stride != 1 || (p.Cin & 63) || p.ksplit != 1 || (p.W & 1) || p.W < 2) return false;
-    if (p.Ho != p.H || p.Wo != p.W) return false;
-    if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2) || p.out2) return false;
-    bool shape = conv3x3_wino_shape_ok(p.W, p.Cin, p.KS, p.stride);
-#ifdef FRP_LAB    // the row-patch form for wide maps (measured slower than the direct kernel, not shipped): only when asked for by
-    shape = shape || ((p.dbg & 64) && conv3x3_wino_lab_shape_ok(p.W, p.Cin, p.KS, p.stride));      // dbg bit 64 (conv_bench / conv2d)
-#endif
-    if (!shape) return false;
+    if (!wino_form(p)) return false;
     const long reach = ((long)p.M + 2L * p.W + 600) * p.Cin * 2;       // signed 32-bit patch offsets
     return reach < 0x7fffffffL;
 }
@@ -992,13 +1054,15 @@ static hipError_t launch_wino_cfg(const ConvParams& p0, hipStream_t stream) {
 template <int VAR>
 static hipError_t launch_wino2_cfg(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
-    p.n_ptiles = (p.M + WN_TP - 1) / WN_TP;
+    constexpr bool T2D = (VAR & 32) != 0;
+    p.n_ptiles = T2D ? p.N * ((p.H + 7) / 8) * ((p.W + 29) / 30) : (p.M + WN_TP - 1) / WN_TP;
     p.n_ctiles = (p.Cout + WN_TC - 1) / WN_TC;
     const size_t img = conv3x3_wino_image_bytes(p.Cin, p.Cout);
     if (img >= 0x7fffffffUL) return hipErrorInvalidValue;
     p.w_bytes = (unsigned)img;
-    if (wino_half_rows(p.W) != WN2_PPW * 32) return hipErrorInvalidValue;          // 5 patch pieces per wave
-    const int lds = wino_lds_bytes(p.W);
+    if (T2D && (p.n_dev || (long)p.N * p.H * p.W != (long)p.M)) return hipErrorInvalidValue;
+    if (!T2D && wino_half_rows(p.W) != WN2_PPW * 32) return hipErrorInvalidValue;          // 5 patch pieces per wave
+    const int lds = wino_lds_bytes(T2D ? 14 : p.W);
     static int attr_lds[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1017,7 +1081,9 @@ static hipError_t launch_wino2_cfg(const ConvParams& p0, hipStream_t stream) {
 }
 
 hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
-    if (!conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
+    const int form = wino_form(p);
+    if (!form || !conv3x3_wino_eligible(p)) return hipErrorInvalidValue;
+    if (form == 2) return launch_wino2_cfg<32>(p, stream);            // 2-D tiles
 #ifdef FRP_LAB   // dbg bit 128: the first generation of the k-loop (compiler-scheduled; A/B partner of the hand-ordered one)
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 13) return launch_wino2_cfg<2>(p, stream);   // sub-step stamps
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 14) return launch_wino2_cfg<1>(p, stream);   // waves 4-7 at priority 1

@@ -110,13 +110,14 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
 // as run-time values the compiler kept ~70 uniform branches and ~90 s_nops in every epilogue (it does not unswitch
 // a body this large), a quarter of its instructions.  Ragged tiles and fp32 output take the generic copy.
 //   ACT: FRP_ACT_* or -1 = run-time p.act;  RES: 0 / 1 or -1 = run-time.
-template <int MP, int MC, int TC, bool FULL, int ACT, int RES>
+template <int MP, int MC, int TC, bool FULL, int ACT, int RES, bool OVER = false>
 __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16 (&acc)[MP][MC], const uint4 (&rres)[MP][MC][2],
                                                    const float* lds_bias, const float* lds_slope, int m0, int c0, int prow0,
                                                    int crow0, int fr, int fh, int HoWo, float inv_howo, float inv_wo,
-                                                   int ps = 1, int po = 0) {
+                                                   int ps = 1, int po = 0, int m_over = 0) {
     // (ps, po): lane row r of the tile holds output pixel m0 + r * ps + po: (1, 0) in the direct kernels, (2, parity) in
-    // the Winograd kernel, whose lanes own pixel PAIRS (conv3x3_wino.hip)
+    // the Winograd kernel, whose lanes own pixel PAIRS (conv3x3_wino.hip).  OVER (MP = 1; the Winograd kernel's 2-D tiles):
+    // the lane's pixel is m_over + po instead, and does not exist when m_over < 0.
     const bool border = p.flags & FRP_FLAG_BORDER_BIAS;
     const bool out32 = (ACT < 0) && (p.flags & FRP_FLAG_OUT_F32);
     const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, floatx16
     int cls[MP];
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
-        const int mraw = m0 + (prow0 + i * 32 + fr) * ps + po;
+        const int mraw = OVER ? (m_over >= 0 ? m_over + po : p.M) : m0 + (prow0 + i * 32 + fr) * ps + po;
         mok[i] = FULL || mraw < p.M;
         const int m = mok[i] ? mraw : 0;
         cls[i] = 0;

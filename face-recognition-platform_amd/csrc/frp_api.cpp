@@ -418,6 +418,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.n_dev = n_dev;
         p.n_cu = h->n_cu;
         p.small_m = small_m;
+        p.wino_wide_only = &net == &h->det ? 1 : 0;
         {
             const size_t oi = (size_t)(&op - net.ops.data());
             if (allow_wino && oi < net.wino_off.size() && net.wino_off[oi] >= 0) p.wino_w = (const _Float16*)(wbase + net.wino_off[oi]);
@@ -612,7 +613,10 @@ int run_detect(frp_handle* h, int K, float det_thresh, float nms_iou, uint32_t f
         if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("preprocess: ") + hipGetErrorString(e));
     }
     rec(h, EV_PRE);
-    FRPCHK(run_net(h, h->det, B, Hc, Wc, &h->ctr.det_conv_flops, &h->ctr.det_conv_launches, fused ? &sp : nullptr));
+    // Winograd family for the detector's wide 128 / 256-channel layers: from two rounds of 8 x 30 tiles on its stride-8 maps on
+    // (1080p: four frames; below that the direct family with its quarter tiles and weight prefetch: single-image latency)
+    const bool det_wino = (long)B * (Hc / 8) * (Wc / 8) >= 2L * 240 * (h->n_cu > 0 ? h->n_cu : 256);
+    FRPCHK(run_net(h, h->det, B, Hc, Wc, &h->ctr.det_conv_flops, &h->ctr.det_conv_launches, fused ? &sp : nullptr, nullptr, det_wino));
     rec(h, EV_DET);
     DecodeParams dp{};
     for (int l = 0; l < 3; ++l) {
@@ -1139,6 +1143,21 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
             build_wino_image(reinterpret_cast<const uint16_t*>(expanded.data() + op.w_off), op.cin, op.cout,
                              reinterpret_cast<uint16_t*>(expanded.data() + dst));
             h->emb.wino_off[i] = (int64_t)dst;
+        }
+        // The detector's maps depend on the frame size, so which of its layers take the kernel (in its 2-D tile form: maps wider than
+        // 30 pixels) is decided per launch (conv3x3_wino.hip: wino_2d_pays); every 3x3 stride-1 layer of 128 channels and more that
+        // could gets an image here (a third more weight bytes for those layers).
+        for (size_t i = 0; i < h->det.ops.size(); ++i) {
+            const frp_conv_op& op = h->det.ops[i];
+            if (op.ksize != 3 || op.stride != 1 || (op.cin & 63) || op.cin < 128 || op.cout < 64 || op.out2_buf >= 0 ||
+                (op.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_FLATTEN | FRP_FLAG_RES_UP2 | FRP_OPFLAG_W_FP8 | FRP_OPFLAG_FP8_MFMA | FRP_OPFLAG_OUT_FP8)))
+                continue;
+            const size_t bytes = conv3x3_wino_image_bytes(op.cin, op.cout);
+            const size_t dst = (expanded.size() + 255) / 256 * 256;
+            expanded.resize(dst + bytes);
+            build_wino_image(reinterpret_cast<const uint16_t*>(expanded.data() + op.w_off), op.cin, op.cout,
+                             reinterpret_cast<uint16_t*>(expanded.data() + dst));
+            h->det.wino_off[i] = (int64_t)dst;
         }
         data = expanded.data();
         data_bytes = expanded.size();
@@ -1943,9 +1962,10 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     const bool want_wino = (flags & 0x10000) != 0;
     std::vector<uint16_t> wimg;
     if (want_wino) {
-        bool shape_ok = conv3x3_wino_shape_ok(W, Cin, ksize, stride);
+        bool shape_ok = conv3x3_wino_shape_ok(W, Cin, ksize, stride) ||
+                        (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu));      // (2-D tiles: wide maps)
 #ifdef FRP_LAB
-        shape_ok = shape_ok || ((((flags >> 8) & 0xff) & 64) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
+        shape_ok = shape_ok || (((((flags >> 8) & 0xff) & 64) || (flags & 0x80000)) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
 #endif
         if (!shape_ok || (flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2)))
             return fail(h, FRP_ERR_INVALID, "shape not covered by the Winograd kernel");
@@ -1969,7 +1989,8 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.out = dout.p;
             p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
-            p.dbg = (flags >> 8) & 0xff;      // kernel A/B switches (tests: 1 = generic kernel instead of the row-patch one)
+            p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0);      // kernel A/B switches (tests: 1 = generic kernel instead of the
+                                                                                // row-patch one; flags bit 19 = dbg 256: the Winograd kernel's 2-D tiles, lab build)
             // flags bit 17 / 18: quarter tiles always / never (default: by the tile count, conv_common.h: conv_small_m)
             p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || want_wino) ? -1 : 0;
             p.Hr = res_h; p.Wr = res_w;
@@ -2077,12 +2098,12 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
             if (!(flags & FRP_FLAG_OUT_FP8)) p.out2 = dr.p;   // conv2-style: fp16 out + fp8 copy (residual buffer doubles as the copy target when unused)
             if (with_res) p.out2 = nullptr;
         }
-        p.dbg = (flags >> 8) & 0xff;
+        p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0);
         p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
-        bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride);
+        bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu));
 #ifdef FRP_LAB
-        wino_shape = wino_shape || ((p.dbg & 64) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
+        wino_shape = wino_shape || ((p.dbg & (64 | 256)) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
 #endif
         if ((flags & 0x10000) && wino_shape) {     // Winograd kernel: a random weight image (timing only)
             const size_t ib = conv3x3_wino_image_bytes(Cin, Cout);

@@ -46,6 +46,8 @@ struct ConvParams {
     int n_cu;               // compute units (input of the device-side split-K choice)
     unsigned long long* stamps;   // conv_bench diagnostics: [grid][8] 100 MHz phase stamps, or null
     int dbg;                // A/B switch (tests, conv_bench): 1 = generic kernel also for row-patch shapes
+    int wino_wide_only;     // the Winograd kernel only in its 2-D tile form (maps wider than its flattened tiles cover) and only where the
+                            // tile arithmetic says it pays (conv3x3_wino.hip: wino_2d_pays) - the detector's layers
     const void* pf_ptr;     // quarter-tile launches with CUs to spare: the NEXT launch's weights (pf_bytes of them), read once by 64 extra
     unsigned pf_bytes;      // workgroups - 8 per XCD - while this launch runs, so that the next one streams them from L2 (a call of a few
     int n_workers;          // faces reads every weight once, cold: its k-steps wait for HBM); n_workers: set by the launcher (0 = the whole grid works)
@@ -69,6 +71,7 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // st
 // the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
 bool conv3x3_wino_eligible(const ConvParams& p);
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride);
+bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu);   // maps wider than 30: the 2-D tile form, where its tile arithmetic pays
 #ifdef FRP_LAB
 bool conv3x3_wino_lab_shape_ok(int W, int Cin, int ksize, int stride);   // + the maps only the lab's row-patch form covers (dbg bit 64)
 #endif

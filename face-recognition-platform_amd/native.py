@@ -362,6 +362,7 @@ class Engine:
         self._chk(self._lib.frp_process_frames(self._h, _ptr(frames), B, H, W, rs, max_faces, det_thresh, nms_iou, flags,
                                                _ptr(o["boxes"]), _ptr(o["kps"]), _ptr(o["scores"]), _ptr(o["counts"]),
                                                _ptr(o["emb"]), _ptr(o["match_idx"]), _ptr(o["match_cos"])))
+        self._det_batch = B
         return o
 
     def upload_frames(self, frames: np.ndarray):

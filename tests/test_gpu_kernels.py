@@ -664,6 +664,41 @@ def test_conv_winograd_parity(engine, case):
     assert np.array_equal(wino.view(np.uint16), again.view(np.uint16))
 
 
+WINO_WIDE_CASES = [
+    # N, H, W, Cin, Cout, act, res, flags(border): maps wider than the flattened tiles cover -> the kernel's 2-D tiles (8 x 30)
+    (4, 136, 240, 128, 128, 1, True, 0),     # det.layer2 at 1080p, four frames: the smallest call that takes them (two rounds of tiles)
+    (8, 68, 120, 256, 256, 1, False, 1),     # det.layer3 shape: ragged tile rows (68 = 8 x 8 + 4), two cout tiles
+    (11, 46, 118, 256, 160, 2, True, 1),     # ragged rows (46 = 5 x 8 + 6), columns (118 = 3 x 30 + 28) and couts, PReLU + residual + border classes
+]
+
+
+@pytest.mark.parametrize("case", WINO_WIDE_CASES)
+def test_conv_winograd_2d_tiles_parity(engine, case):
+    """The Winograd kernel on maps wider than 30 pixels (round 4: tiles of 8 rows x 30 columns of one image - the flattened kernel on
+    a 32-wide virtual strip; conv3x3_wino.hip: VAR & 32): same bars as the flattened form - 2e-3 of the output scale against
+    the fp32 reference, 3 fp16 ulps of the scale against the direct kernel, the same bits on a second launch."""
+    N, H, W, Cin, Cout, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 11)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
+    bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, Cout).astype(np.float32) if act == 2 else None
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if has_res else None
+    direct = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT)
+    wino = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | 0x10000)
+    ref = _conv_ref(x, w, bias, 1, act, slope, res, flags)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(wino.astype(np.float32) - ref).max() <= 2e-3 * scale
+    d = np.abs(wino.astype(np.float32) - direct.astype(np.float32))
+    assert d.max() <= 3 * 2.0 ** -10 * scale
+    assert d.max() > 0                                                   # (it IS the other kernel family)
+    again = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | 0x10000)
+    assert np.array_equal(wino.view(np.uint16), again.view(np.uint16))
+    # a call of fewer than two rounds of tiles is refused (the engine takes the direct family there), not silently rerouted
+    with pytest.raises(Exception):
+        engine.conv2d(x[:1], w, bias, stride=1, act=act, slope=slope, res=None if res is None else res[:1], flags=flags | 0x10000)
+
+
 def test_conv_winograd_ring_stress(engine):
     """The Winograd kernel's rings under timing pressure (round 4: the weight ring runs three sub-steps ahead and a slot is
     restaged by the sub-step that computes on the fragments read from it; round 3's review: no stress configuration of its

@@ -105,6 +105,48 @@ def test_full_size_end_to_end_1080p_r100_vs_oracle(engine):
     print("full-size end to end:", n, "faces, 1 - cos max", float(1 - cos.min()), "box err", float(np.abs(out["boxes"][0, :n] - r["boxes"]).max()))
 
 
+def test_detector_on_winograd_2d_tiles_agrees_with_the_direct_family_at_1080p(engine, monkeypatch):
+    """From four 1080p frames per call on, the detector's wide 128 / 256-channel 3x3 layers take the Winograd kernel's 2-D tiles
+    (frp_api.cpp: det_wino; conv3x3_wino.hip: wino_2d_pays).  The same four frames with FRP_NO_WINO=1 (direct family, the one the
+    oracle test above pins) give: head maps within 6 fp16 ulps of their scale (and NOT the same bits: the other family did
+    run), the same detections in the same order, boxes / landmarks within 0.25 px (half the bar against the oracle), scores 2e-3, embeddings of the (slightly differently) aligned chips cos >= 0.98;
+    one frame alone (direct family either way) is bit for bit its slot of the FRP_NO_WINO batch."""
+    rng = np.random.default_rng(77)
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    H, W, K = 1080, 1920, 8
+    fr = _frames(rng, 4, H, W)
+    G = rng.standard_normal((2000, 512)).astype(np.float32)
+    thr, _ = _threshold_with_margin(raw, fr[:1], (1088, 1920), lo_cnt=2, hi_cnt=40)
+    monkeypatch.setenv("FRP_NO_WINO", "1")
+    engine.load_weights(blob)
+    engine.gallery_set(G)
+    a = engine.process_frames(fr, max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+    ha = [h.astype(np.float32) for h in engine.head_maps()]
+    one = engine.process_frames(fr[2:3], max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+    monkeypatch.delenv("FRP_NO_WINO")
+    engine.load_weights(blob)
+    engine.gallery_set(G)
+    b = engine.process_frames(fr, max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+    hb = [h.astype(np.float32) for h in engine.head_maps()]
+    one_b = engine.process_frames(fr[2:3], max_faces=K, det_thresh=float(thr), nms_iou=0.4)
+    differs = False
+    for x, y in zip(ha, hb):
+        scale = max(1.0, float(np.abs(x).max()))
+        assert np.abs(x - y).max() <= 6 * 2.0 ** -10 * scale
+        differs = differs or not np.array_equal(x, y)
+    assert differs
+    assert np.array_equal(a["counts"], b["counts"]) and int(a["counts"].sum()) >= 4
+    for i, n in enumerate(a["counts"]):
+        assert np.abs(a["boxes"][i, :n] - b["boxes"][i, :n]).max(initial=0) < 0.25     # (an fp16 ulp of a stride-32 offset is 0.06 px)
+        assert np.abs(a["kps"][i, :n] - b["kps"][i, :n]).max(initial=0) < 0.25
+        assert np.abs(a["scores"][i, :n] - b["scores"][i, :n]).max(initial=0) < 2e-3
+        if n:       # (downstream of landmarks that moved by up to 0.1 px: a seeded random embedder on noise-like chips is far more
+            assert (a["emb"][i, :n] * b["emb"][i, :n]).sum(1).min() > 0.98       # sensitive to that than a trained one on faces)
+    for k in ("boxes", "kps", "scores", "counts", "emb", "match_idx"):
+        assert np.array_equal(one[k][0], a[k][2]), k                        # a frame's result in the direct family: independent of the batch
+        assert np.array_equal(one[k], one_b[k]), k                          # and a call of one frame never takes the 2-D tiles
+
+
 def test_threshold_mode_face_count_stays_on_the_device(engine, monkeypatch):
     """Threshold mode (routes/camera.py:232-259: the reference's loop) without the mid-pipeline host round trip: align,
     embedder, l2norm and matcher read the face count from device memory.  Bit for bit the results of the former path

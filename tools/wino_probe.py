@@ -33,12 +33,15 @@ def main():
     tot = [0.0, 0.0, 0.0]
     for name, N, H, W, Ci, Co, act, fl, res in SHAPES:
         variants = [0, 0x10000, 0x10000 | (128 << 8)] + [0x10000 | ((int(x) << 1) << 8) for x in os.environ.get("WINO_VARIANTS", "").split(",") if x]
+        t2d = len(variants) if os.environ.get("WINO_T2D") else -1          # + the 2-D tiles (8 x 30; flags bit 19), every shape
+        if t2d >= 0:
+            variants.append(0x10000 | 0x80000)
         best = [1e30] * len(variants)
         for _ in range(3):
             # direct, Winograd (hand-ordered k-loop, round 4), Winograd first generation (compiler-scheduled k-loop: dbg bit 128),
             # + lab variants of the hand-ordered loop (WINO_VARIANTS=14,12: dbg codes)
             for v, extra in enumerate(variants):
-                if v >= 2 and W > 30:                                          # (wide maps: the row-patch form is first generation anyway)
+                if v >= 2 and W > 30 and v != t2d:                             # (wide maps: the row-patch form is first generation anyway)
                     best[v] = float("nan")
                     continue
                 if v == 1 and W > 30:
