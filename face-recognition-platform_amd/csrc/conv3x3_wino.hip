@@ -976,9 +976,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
 // A tile carries 240 real pixels in 256 pixel slots and the edge tiles of a map carry less; against that stand the kernel's x1.12
 // (128 channels: 24 sub-steps per tile, a third of a tile is prologue + epilogue) and x1.2 (256 channels and more) over the direct
 // kernel.  Measured (tools/wino_probe.py, 32 frames): 136 x 240 x 128: x1.08-1.11, 68 x 120 x 256: x1.09, 68 x 120 x 128: x1.00,
-// 34 x 60 x 256: x0.98.  Fewer than two rounds of tiles: the direct family (its quarter tiles fill the chip better).
-bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu) {
+// 34 x 60 x 256: x0.98; with a residual at 128 channels x1.08 alone but nothing in the pipeline.  Fewer than two rounds of tiles: the
+// direct family (its quarter tiles fill the chip better).
+bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu, bool has_res) {
     if ((W & 1) || W <= 30 || Cin < 128 || (Cin & 63)) return false;
+    if (has_res && Cin < 256) return false;     // (in the pipeline the 136 x 240 x 128 residual layers ran 302 / 318 us against 310 / 305 direct)
     const long ty = (H + 7) / 8, tx = (W + 29) / 30;
     const long tiles = (long)N * ty * tx * ((Cout + WN_TC - 1) / WN_TC);
     if (tiles < 2L * (n_cu > 0 ? n_cu : 256)) return false;
@@ -986,7 +988,7 @@ bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu) {
     return (Cin >= 256 ? 1.2 : 1.12) * real / slots >= 1.03;
 }
 static bool wino_2d_pays(const ConvParams& p) {
-    return !p.n_dev && (long)p.N * p.H * p.W == (long)p.M && conv3x3_wino_wide_pays(p.N, p.H, p.W, p.Cin, p.Cout, p.n_cu);
+    return !p.n_dev && (long)p.N * p.H * p.W == (long)p.M && conv3x3_wino_wide_pays(p.N, p.H, p.W, p.Cin, p.Cout, p.n_cu, p.res != nullptr);
 }
 
 // which form of the kernel a launch takes: 0 none, 1 flattened tiles (maps up to 30 wide), 2 the 2-D tiles

@@ -1963,7 +1963,7 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
     std::vector<uint16_t> wimg;
     if (want_wino) {
         bool shape_ok = conv3x3_wino_shape_ok(W, Cin, ksize, stride) ||
-                        (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu));      // (2-D tiles: wide maps)
+                        (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu, res != nullptr));      // (2-D tiles: wide maps)
 #ifdef FRP_LAB
         shape_ok = shape_ok || (((((flags >> 8) & 0xff) & 64) || (flags & 0x80000)) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
 #endif
@@ -2101,7 +2101,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
         p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0);
         p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
-        bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu));
+        bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu, with_res != 0));
 #ifdef FRP_LAB
         wino_shape = wino_shape || ((p.dbg & (64 | 256)) && conv3x3_wino_lab_shape_ok(W, Cin, ksize, stride));
 #endif

@@ -71,7 +71,7 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // st
 // the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
 bool conv3x3_wino_eligible(const ConvParams& p);
 bool conv3x3_wino_shape_ok(int W, int Cin, int ksize, int stride);
-bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu);   // maps wider than 30: the 2-D tile form, where its tile arithmetic pays
+bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu, bool has_res);   // maps wider than 30: the 2-D tile form, where its tile arithmetic pays
 #ifdef FRP_LAB
 bool conv3x3_wino_lab_shape_ok(int W, int Cin, int ksize, int stride);   // + the maps only the lab's row-patch form covers (dbg bit 64)
 #endif

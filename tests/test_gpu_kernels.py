@@ -666,8 +666,8 @@ def test_conv_winograd_parity(engine, case):
 
 WINO_WIDE_CASES = [
     # N, H, W, Cin, Cout, act, res, flags(border): maps wider than the flattened tiles cover -> the kernel's 2-D tiles (8 x 30)
-    (4, 136, 240, 128, 128, 1, True, 0),     # det.layer2 at 1080p, four frames: the smallest call that takes them (two rounds of tiles)
-    (8, 68, 120, 256, 256, 1, False, 1),     # det.layer3 shape: ragged tile rows (68 = 8 x 8 + 4), two cout tiles
+    (4, 136, 240, 128, 128, 1, False, 0),    # det.layer2 at 1080p, four frames: the smallest call that takes them (two rounds of tiles)
+    (8, 68, 120, 256, 256, 1, True, 1),      # det.layer3 shape + residual: ragged tile rows (68 = 8 x 8 + 4), two cout tiles
     (11, 46, 118, 256, 160, 2, True, 1),     # ragged rows (46 = 5 x 8 + 6), columns (118 = 3 x 30 + 28) and couts, PReLU + residual + border classes
 ]
 

@@ -113,10 +113,10 @@ def test_detector_on_winograd_2d_tiles_agrees_with_the_direct_family_at_1080p(en
     one frame alone (direct family either way) is bit for bit its slot of the FRP_NO_WINO batch."""
     rng = np.random.default_rng(77)
     raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
-    H, W, K = 1080, 1920, 8
+    H, W, K = 1080, 1920, 16
     fr = _frames(rng, 4, H, W)
     G = rng.standard_normal((2000, 512)).astype(np.float32)
-    thr, _ = _threshold_with_margin(raw, fr[:1], (1088, 1920), lo_cnt=2, hi_cnt=40)
+    thr, _ = _threshold_with_margin(raw, fr, (1088, 1920), lo_cnt=1, hi_cnt=60)       # a logit gap over all four frames
     monkeypatch.setenv("FRP_NO_WINO", "1")
     engine.load_weights(blob)
     engine.gallery_set(G)
@@ -137,11 +137,18 @@ def test_detector_on_winograd_2d_tiles_agrees_with_the_direct_family_at_1080p(en
     assert differs
     assert np.array_equal(a["counts"], b["counts"]) and int(a["counts"].sum()) >= 4
     for i, n in enumerate(a["counts"]):
-        assert np.abs(a["boxes"][i, :n] - b["boxes"][i, :n]).max(initial=0) < 0.25     # (an fp16 ulp of a stride-32 offset is 0.06 px)
-        assert np.abs(a["kps"][i, :n] - b["kps"][i, :n]).max(initial=0) < 0.25
-        assert np.abs(a["scores"][i, :n] - b["scores"][i, :n]).max(initial=0) < 2e-3
-        if n:       # (downstream of landmarks that moved by up to 0.1 px: a seeded random embedder on noise-like chips is far more
-            assert (a["emb"][i, :n] * b["emb"][i, :n]).sum(1).min() > 0.98       # sensitive to that than a trained one on faces)
+        if not n:
+            continue
+        # the same faces; their order (descending score) may differ where two scores are closer than the families' 1e-3
+        d = np.abs(a["boxes"][i, :n, None, :] - b["boxes"][i, None, :n, :]).max(-1)
+        j = d.argmin(1)
+        assert sorted(j.tolist()) == list(range(n)), (i, j)
+        assert d[np.arange(n), j].max() < 0.25                              # (an fp16 ulp of a stride-32 offset is 0.06 px)
+        assert np.abs(a["kps"][i, :n] - b["kps"][i, j]).max() < 0.25
+        assert np.abs(a["scores"][i, :n] - b["scores"][i, j]).max() < 2e-3
+        # (downstream of landmarks that moved by up to 0.1 px: a seeded random embedder on noise-like chips is far more sensitive to
+        # that than a trained one on faces)
+        assert (a["emb"][i, :n] * b["emb"][i, j]).sum(1).min() > 0.98
     for k in ("boxes", "kps", "scores", "counts", "emb", "match_idx"):
         assert np.array_equal(one[k][0], a[k][2]), k                        # a frame's result in the direct family: independent of the batch
         assert np.array_equal(one[k], one_b[k]), k                          # and a call of one frame never takes the 2-D tiles
