@@ -67,10 +67,9 @@ __device__ __forceinline__ void wino_load_res(const ConvParams& p, uint4 (&r)[PB
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
         const int mraw = OVER ? (m_over >= 0 ? m_over + par : p.M) : m0 + (pair0 + b * 32 + fr) * 2 + par;
-        int m = mraw < p.M ? mraw : 0;
-#ifdef FRP_LAB   // dbg code 8 (wrong results by design): every tile reads the residual of the first 256 pixels - an L2-resident
-        if (((p.dbg >> 1) & 15) == 8) m &= 255;                  // 64 KiB: what the epilogue would cost if the residual came from L2
-#endif
+        const int m = mraw < p.M ? mraw : 0;
+        // (round 4, lab experiment since removed: every tile's residual read from the same L2-resident 64 KiB - the best any prefetch
+        // could do - took stage 3 conv2 from 59.5 to 58.4 us, stage 2 conv2 from 75.5 to 71.4: profiles/r4/wino_probe_residual_from_l2.txt)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int co = c0 + crow0 + c * 32 + 16 * q + 8 * fh;
@@ -1093,7 +1092,7 @@ hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 11) return launch_wino2_cfg<8>(p, stream);   // DMA by waves 0-3 only
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 10) return launch_wino2_cfg<16>(p, stream);  // ring two ahead
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 9) return launch_wino2_cfg<9>(p, stream);    // DMA by waves 0-3, waves 4-7 at priority 1
-    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && (!((p.dbg >> 1) & 15) || ((p.dbg >> 1) & 15) == 8)) return launch_wino2_cfg<0>(p, stream);
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && !((p.dbg >> 1) & 15)) return launch_wino2_cfg<0>(p, stream);
 #else
     return wino_super_patch(p.W) ? launch_wino2_cfg<0>(p, stream) : hipErrorInvalidValue;
 #endif
