@@ -742,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     // ---------------- prologue: patch of the first tile's first channel block, weight stages 0..3
     unsigned clkk = 0;                         // (lab, VAR & 2: shader clock and 100 MHz clock at kernel start / end in its lanes 8..15)
     if constexpr (VAR & 2) { if (p.stamps && blockIdx.x < 32) { wn2_clock<4>(clkk); wn2_clock_real<5>(clkk); } }
-    else stamp(p.stamps, 0);
+    else if constexpr (VAR & 64) stamp(p.stamps, 0);          // (100 MHz phase stamps: lab variant VAR & 64 only - the stamp address is a
+                                                              //  per-lane value the shipped kernel would keep spilled from start to end)
     if (t < 64) reinterpret_cast<unsigned*>(smem + OFF_Z)[t] = 0u;
     Tile cur, nt;
     make_tile(t0, cur);
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     wait_vmcnt<AHEAD * WPW>();              // patch and stage 0 are in
     __syncthreads();
     first_operands(cur, 0);
-    if constexpr (!(VAR & 2)) stamp(p.stamps, 1);
+    if constexpr (VAR & 64) stamp(p.stamps, 1);
 
     for (int ct = t0; ct < t1; ct += tstep) {
 #pragma unroll
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             for (int i = 0; i < 4; ++i) rad[i] = abase[kh][i] + ((okm >> (kh * 4 + i)) & 1u ? (unsigned)xslot : 0u);
         };
         rad_of(0, xs);
-        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 2); }
+        if constexpr (VAR & 64) { if (ct == t0) stamp(p.stamps, 2); }
 
         for (int cb = 0; cb < cpt; ++cb) {
             const bool last_cb = cb + 1 == cpt;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             xs ^= XSLOT;
         }
 
-        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 4); }
+        if constexpr (VAR & 64) { if (ct == t0) stamp(p.stamps, 4); }
         // the epilogue reads the accumulators with vector instructions: the last MFMAs must have left the matrix pipe (the
         // compiler pads what it schedules itself, not what sits in asm statements)
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
@@ -944,7 +945,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
                 m_over = (cur.vmask & 1u) ? mt_cur + (pl >> 4) * p.W + 2 * (pl & 15) : -1;
             }
             const bool full = !T2D && m0 + TP <= p.M && c0 + TC <= p.Cout;
-            if (T2D && c0 + TC <= p.Cout) {
+            if ((T2D || m0 + TP > p.M) && c0 + TC <= p.Cout) {      // masked stores, still specialised (the run-time form below keeps both the
+                                                                     // slope and the residual path alive: it is the one that spills)
                 if (p.act == FRP_ACT_PRELU) { if (has_res) WN_EPI(false, FRP_ACT_PRELU, 1); else WN_EPI(false, FRP_ACT_PRELU, 0); }
                 else if (p.act == FRP_ACT_RELU) { if (has_res) WN_EPI(false, FRP_ACT_RELU, 1); else WN_EPI(false, FRP_ACT_RELU, 0); }
                 else { if (has_res) WN_EPI(false, FRP_ACT_NONE, 1); else WN_EPI(false, FRP_ACT_NONE, 0); }
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         cur = nt;
         if constexpr (T2D) mt_cur = mt_nxt;
         if (ct + tstep < t1) first_operands(cur, xs);       // (its patch and stage 0 landed before this tile's last barrier)
-        if constexpr (!(VAR & 2)) { if (ct == t0) stamp(p.stamps, 5); }
+        if constexpr (VAR & 64) { if (ct == t0) stamp(p.stamps, 5); }
     }
     // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
     wait_vmcnt<0>();
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             wn2_clock_real<7>(clkk);
             if (lane >= 8 && lane < 16) reinterpret_cast<unsigned*>(p.stamps)[((long)blockIdx.x * 8 + wave) * 16 + lane] = clkk;
         }
-    } else stamp(p.stamps, 6);
+    } else if constexpr (VAR & 64) stamp(p.stamps, 6);
 }
 
 // 2-D tiles (8 rows x 30 columns of one image; conv3x3_wino2_kernel<32>) for maps wider than the flattened tiles cover: where they pay.
@@ -1087,6 +1089,7 @@ hipError_t launch_conv3x3_wino(const ConvParams& p, hipStream_t stream) {
     if (form == 2) return launch_wino2_cfg<32>(p, stream);            // 2-D tiles
 #ifdef FRP_LAB   // dbg bit 128: the first generation of the k-loop (compiler-scheduled; A/B partner of the hand-ordered one)
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 13) return launch_wino2_cfg<2>(p, stream);   // sub-step stamps
+    if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 8) return launch_wino2_cfg<64>(p, stream);   // 100 MHz phase stamps
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 14) return launch_wino2_cfg<1>(p, stream);   // waves 4-7 at priority 1
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 12) return launch_wino2_cfg<4>(p, stream);   // priority falls with progress
     if (!(p.dbg & 128) && wino_super_patch(p.W) && !(p.dbg & (32 | 64)) && ((p.dbg >> 1) & 15) == 11) return launch_wino2_cfg<8>(p, stream);   // DMA by waves 0-3 only

@@ -11,6 +11,8 @@ a = [int(x) for x in sys.argv[1:8]] if len(sys.argv) > 7 else [320, 14, 14, 256,
 eng = native.Engine(0)
 res = len(sys.argv) > 8 and "res" in sys.argv[8:]
 extra = (0x10000 if "wino" in sys.argv[8:] else 0) | ((32 << 8) if "wino4" in sys.argv[8:] else 0)     # Winograd kernel (8 / 4 waves)
+if "wino" in sys.argv[8:] and "wino4" not in sys.argv[8:]:
+    extra |= (8 << 1) << 8            # the hand-ordered kernel carries the phase stamps in its lab variant only (dbg code 8)
 ms, st = eng.conv_bench(a[0], a[1], a[2], a[3], a[4], a[5], a[6], 0 if res else 2, 1 | extra, res, 20, stamps=True)
 st = st[st[:, 0] > 0].astype(np.int64)
 t0 = st[:, 0].min()
