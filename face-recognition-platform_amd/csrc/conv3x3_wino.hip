@@ -633,6 +633,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     const u32x4 xrsrc = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
     const u32x4 wrsrc = {(unsigned)wa, (unsigned)(wa >> 32) & 0xffffu, p.w_bytes, 0x00020000u};
 
+    // The first tile's weight stages 0..AHEAD go out before anything else is set up: their operands are a handful of scalars, and the
+    // ~1.3 us until a first stage has landed then run under the rest of the prologue (lane geometry, masks, the patch's addresses)
+    // instead of behind it.  (The patch pieces follow below, so the in-order counter holds: stages, then patch - see the wait.)
+    {
+        constexpr int NDW0 = (VAR & 8) ? 4 : 8, WPW0 = 16 / NDW0;
+        const int wbase0 = (t0 % p.n_ctiles) * cpt * 12 * WN_WSLOT;
+        if (!(VAR & 8) || wave < 4) {
+#pragma unroll
+            for (int st = 0; st < (AHEAD + 1); ++st)
+#pragma unroll
+                for (int j = 0; j < WPW0; ++j)
+                    wn2_dma(wrsrc, lds0 + OFF_W + st * WN_WSLOT + (wave + NDW0 * j) * 1024, (unsigned)(lane * 16),
+                            (unsigned)(wbase0 + st * WN_WSLOT + (wave + NDW0 * j) * 1024));
+        }
+    }
+
     // ---------------- DMA lane geometry (as the first generation): a piece fills 8 LDS rows x 128 B, lane -> row lane / 8,
     // 16-byte position lane % 8 holding logical chunk pos ^ ((row >> 1) & 7) (source-side swizzle)
     const int lrow = lane >> 3;
@@ -753,12 +769,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         if (dma_wave) {
 #pragma unroll
             for (int j = 0; j < XPW; ++j) wn2_dma(xrsrc, lds0 + (wave + NDW * j) * 1024, xb0 + sxo[j], 0u);
-#pragma unroll
-            for (int st = 0; st < (AHEAD + 1); ++st)
-#pragma unroll
-                for (int j = 0; j < WPW; ++j)
-                    wn2_dma(wrsrc, lds0 + OFF_W + st * WN_WSLOT + (wave + NDW * j) * 1024, (unsigned)(lane * 16),
-                            (unsigned)(cur.wbase + st * WN_WSLOT + (wave + NDW * j) * 1024));
         }
     }
     int xs = 0;                                // byte offset of the patch slot the running channel block reads
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         V[0][2] = wn2_sub(raw[2], raw[1]);
         V[0][3] = wn2_sub(raw[1], raw[3]);
     };
-    wait_vmcnt<AHEAD * WPW>();              // patch and stage 0 are in
+    wait_vmcnt<0>();                        // the patch - the youngest of the prologue's requests - is in, and with it stages 0..AHEAD
     __syncthreads();
     first_operands(cur, 0);
     if constexpr (VAR & 64) stamp(p.stamps, 1);
