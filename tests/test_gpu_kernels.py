@@ -722,7 +722,8 @@ def test_conv_winograd_ring_stress(engine):
     th.start()
     try:
         for (N, H, W, Cin, Cout, act, has_res, flags) in ((600, 14, 14, 256, 256, 2, False, 1), (333, 14, 14, 192, 128, 0, True, 0),
-                                                           (170, 28, 28, 64, 256, 1, True, 0), (41, 30, 30, 128, 136, 2, False, 1)):
+                                                           (170, 28, 28, 64, 256, 1, True, 0), (41, 30, 30, 128, 136, 2, False, 1),
+                                                           (8, 68, 120, 256, 256, 1, True, 0)):       # (the last: the 2-D tiles)
             x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
             w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
             bias = rng.standard_normal((9, Cout) if flags & 1 else (Cout,)).astype(np.float32) * 0.3

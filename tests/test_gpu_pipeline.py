@@ -1011,6 +1011,28 @@ def test_jpeg_stills_decode_on_the_device(engine):
         got = device_decode(imgs)
         for b in range(2):
             assert np.array_equal(got[b], pil_bgr(imgs[b])), (h, w, kw)
+    # awkward sizes (not a multiple of the MCU in either direction, a single MCU column, one pixel more than whole MCUs), every
+    # sampling, grayscale, restart intervals, no Huffman tables in the file (Motion-JPEG frames: the Annex K tables implied)
+    def strip_dht(d):
+        out, i = bytearray(d[:2]), 2
+        while True:
+            m_, L = d[i + 1], (d[i + 2] << 8) | d[i + 3]
+            if m_ == 0xDA:
+                return bytes(out + d[i:])
+            if m_ != 0xC4:
+                out += d[i:i + 2 + L]
+            i += 2 + L
+    for (h, w) in ((33, 47), (64, 66), (65, 64), (97, 16), (129, 255)):
+        img = np.clip(rng.normal(120, 60, (h // 4 + 1, w // 4 + 1, 3)).repeat(4, 0).repeat(4, 1)[:h, :w] + rng.normal(0, 8, (h, w, 3)), 0, 255).astype(np.uint8)
+        for kw in (dict(quality=90, subsampling=0), dict(quality=80, subsampling=1), dict(quality=85, subsampling=2),
+                   dict(quality=75, subsampling=2, restart_marker_blocks=2), dict(quality=92, gray=True), dict(quality=85, subsampling=2, bare=True)):
+            kw = dict(kw)
+            gray, bare = kw.pop("gray", False), kw.pop("bare", False)
+            b = io.BytesIO()
+            (Image.fromarray(img).convert("L") if gray else Image.fromarray(img)).save(b, "JPEG", **kw)
+            data = strip_dht(b.getvalue()) if bare else b.getvalue()
+            got = device_decode([data, data])
+            assert np.array_equal(got[0], pil_bgr(data)) and np.array_equal(got[1], got[0]), (h, w, kw, gray, bare)
     # refused, nothing staged: mixed geometry, a progressive file, not a JPEG
     small = open(stills[0], "rb").read()
     with pytest.raises(FrpError, match="geometry"):
