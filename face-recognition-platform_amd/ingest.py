@@ -52,7 +52,8 @@ def device_jpeg_batch(sources: Sequence[Source], batch: int, hw: Tuple[int, int]
         if isinstance(s, str):
             with open(s, "rb") as f:
                 s = f.read()
-        s = bytes(s)
+        if not isinstance(s, bytes):               # (a bytes subclass - mjpeg.JpegFrame - is passed on as it is: no copy)
+            s = bytes(s)
         info = native.jpeg_info(s)
         if info is None or (info["height"], info["width"]) != tuple(hw):
             return None

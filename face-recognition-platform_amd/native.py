@@ -67,12 +67,27 @@ class JpegInfo(C.Structure):
                 "v_samp": list(self.v_samp), "mcus_x": self.mcus_x, "mcus_y": self.mcus_y, "restart_interval": self.restart_interval}
 
 
+def _byte_ptr(data):
+    """(pointer, keep-alive) to the bytes of `data` without copying them where the object allows it (bytes and its subclasses:
+    the object's own buffer; a bytearray: its buffer; anything else is copied once).  A 1080p JPEG is ~0.7 MB and a batch holds
+    32 of them: per-call copies were tens of megabytes of memcpy on the thread that feeds the lane."""
+    if isinstance(data, bytes):
+        p = C.c_char_p(data)
+        return C.cast(p, C.c_void_p), (p, data)
+    if isinstance(data, bytearray):
+        buf = (C.c_char * len(data)).from_buffer(data)
+        return C.cast(buf, C.c_void_p), buf
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    return C.cast(buf, C.c_void_p), buf
+
+
 def jpeg_info(data: bytes):
     """header of a baseline JPEG as the library's decoder sees it, or None when it does not cover the file (progressive,
     arithmetic-coded, 12-bit, CMYK, multi-scan): include/frp.h frp_jpeg_info_get.  Needs no GPU."""
     info = JpegInfo()
-    buf = (C.c_char * len(data)).from_buffer_copy(data)
-    rc = load_library().frp_jpeg_info_get(C.cast(buf, C.c_void_p), len(data), C.byref(info))
+    ptr, keep = _byte_ptr(data)
+    rc = load_library().frp_jpeg_info_get(ptr, len(data), C.byref(info))
+    del keep
     return info.as_dict() if rc == 0 else None
 
 
@@ -85,8 +100,9 @@ def jpeg_coefficients(data: bytes):
     coef = np.zeros(n, np.int16)
     q = np.zeros((3, 64), np.uint16)
     ji = JpegInfo()
-    buf = (C.c_char * len(data)).from_buffer_copy(data)
-    rc = load_library().frp_jpeg_coefficients(C.cast(buf, C.c_void_p), len(data), _ptr(coef), n, _ptr(q), C.byref(ji))
+    ptr, keep = _byte_ptr(data)
+    rc = load_library().frp_jpeg_coefficients(ptr, len(data), _ptr(coef), n, _ptr(q), C.byref(ji))
+    del keep
     if rc != 0:
         raise FrpError(rc, "corrupt JPEG scan data")
     return info, coef, q
@@ -288,10 +304,11 @@ class Engine:
         threads, dequantisation / inverse DCT / chroma upsampling / YCbCr -> BGR on the GPU's copy stream (frp.h:
         frp_upload_jpeg_async).  Follow with swap_frames() as after upload_frames_async()."""
         B = len(jpegs)
-        bufs = [(C.c_char * len(j)).from_buffer_copy(j) for j in jpegs]
-        ptrs = (C.c_void_p * B)(*[C.cast(b, C.c_void_p) for b in bufs])
+        held = [_byte_ptr(j) for j in jpegs]                      # no copies: the call reads the callers' buffers (and returns after it has)
+        ptrs = (C.c_void_p * B)(*[h[0] for h in held])
         sizes = (C.c_size_t * B)(*[len(j) for j in jpegs])
         self._chk(self._lib.frp_upload_jpeg_async(self._h, ptrs, sizes, B))
+        del held
         info = jpeg_info(jpegs[0])
         self._staged = (B, info["height"], info["width"])
 
