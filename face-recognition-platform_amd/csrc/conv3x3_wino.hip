@@ -526,8 +526,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_wino_kernel(ConvParam
 // sub-steps after the last read of it was consumed.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// ZERO: the first MFMA into an accumulator of a tile - C is the inline constant 0, the accumulator is only written (no 128 v_mov
+// per wave and tile to clear it first; early-clobber: the destination may not overlap the sources)
+template <bool ZERO = false>
 __device__ __forceinline__ void wn2_mfma(floatx16& acc, const half8& a, const half8& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 template <int OFF>
 __device__ __forceinline__ void wn2_read(half8& d, unsigned addr) {
@@ -562,6 +566,8 @@ __device__ __forceinline__ half8 wn2_sub(const half8& a, const half8& b) {
     return __builtin_bit_cast(half8, r);
 }
 template <int T> struct wn2_step_tag { static constexpr int value = T; };
+struct wn2_true { static constexpr bool value = true; };
+struct wn2_false { static constexpr bool value = false; };
 // lab build, VAR & 2: shader-clock stamps inside ONE sub-step (tools/wino_substep.py); s_memtime returns through lgkmcnt, out of
 // order with the LDS reads: the values are only read behind an lgkmcnt(0) at the end of the sampled sub-steps
 // (a result still in flight at the end of an asm statement may be copied - spilled to a vector lane - before it has arrived, and
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             const int pl = pair0 + fr_e, y = y0 + (pl >> 4), x = x0 + 2 * (pl & 15);
             unsigned mask = 0;
             if ((pl & 15) < 15 && y < p.H && x < p.W)
-                mask = 1u | (y > 0 ? 2u : 0u) | (y < p.H - 1 ? 4u : 0u) | (x > 0 ? 8u : 0u) | (x + 2 < p.W ? 16u : 0u);
+                mask = 1u | (y > 0 ? 2u : 0u) | (y + 1 < p.H ? 4u : 0u) | (x > 0 ? 8u : 0u) | (x + 2 < p.W ? 16u : 0u);
             d.vmask = mask;
             return;
         }
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             int n, rem, oy, ox;
             fast_divmod(m, HoWo, inv_howo, n, rem);
             fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-            mask = 1u | (oy > 0 ? 2u : 0u) | (oy < p.H - 1 ? 4u : 0u) | (ox > 0 ? 8u : 0u) | (ox + 2 < p.W ? 16u : 0u);
+            mask = 1u | (oy > 0 ? 2u : 0u) | (oy + 1 < p.H ? 4u : 0u) | (ox > 0 ? 8u : 0u) | (ox + 2 < p.W ? 16u : 0u);
         }
         d.vmask = mask;
     };
@@ -793,12 +799,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     if constexpr (VAR & 64) stamp(p.stamps, 1);
 
     for (int ct = t0; ct < t1; ct += tstep) {
+        // (flattened tiles: the accumulators are not cleared - the tile's first sub-step writes them with C = 0, wn2_mfma<true>: 128 v_mov
+        // per wave and tile less, and with them gone the compiler moves the tile's address set-up into the first sub-step's gaps;
+        // in the 2-D form the same change made the allocator spill four registers and cost more than it saved)
+        if constexpr (T2D) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[f][c][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[f][c][e] = 0.f;
+        }
         const int ptile = ct / p.n_ctiles;
         const int m0 = ptile * TP;
         const int c0 = (ct - ptile * p.n_ctiles) * TC;
@@ -828,7 +839,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
         rad_of(0, xs);
         if constexpr (VAR & 64) { if (ct == t0) stamp(p.stamps, 2); }
 
-        for (int cb = 0; cb < cpt; ++cb) {
+        auto block = [&](int cb, auto first_tag) {          // one 64-channel block = 12 sub-steps; first_tag: the tile's first block
+            constexpr bool FIRST_CB = decltype(first_tag)::value;
             const bool last_cb = cb + 1 == cpt;
             // what lies beyond this channel block: the next block of this tile, or block 0 of the next tile
             const int nxm0b = last_cb ? nt.m0b : cur.m0b;
@@ -851,6 +863,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             const bool sample = (VAR & 2) && p.stamps && blockIdx.x < 32 && ct == t0 && cb == (cpt > 1 ? 1 : 0);
             auto step = [&](auto tag) {
                 constexpr int T = decltype(tag)::value;
+                constexpr bool Z = FIRST_CB && T == 0 && !T2D;                  // the first MFMA into every accumulator of the tile
                 constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;
                 constexpr int P = T & 1, Q = P ^ 1;
                 constexpr int SLN = (T + 1) & 3;                               // ring slot of stage T + 1
@@ -880,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
                 wn2_barrier();
                 if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<2>(clk); }
                 if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(3);         // (lab) the wave that is behind in its sub-step wins the issue arbitration
-                wn2_mfma(acc[0][0], U[P][0], V[P][0]);
+                wn2_mfma<Z>(acc[0][0], U[P][0], V[P][0]);
                 if constexpr (T == 0) { if (cb == 0) dma_params(ct); }         // (visible from the barrier of sub-step 2 on; the previous
                                                                                //  tile's epilogue, the last reader, lies before this barrier)
                 // (T = 11 of a tile's last channel block requests the next tile's first operands like any other sub-step, but nothing is
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
                     wn2_read<0>(raw[0], a0);
                     wn2_read<0>(raw[1], a1);
                 }
-                wn2_mfma(acc[0][1], U[P][1], V[P][0]);
+                wn2_mfma<Z>(acc[0][1], U[P][1], V[P][0]);
                 {
                     const unsigned a2 = rad[2] ^ (KKN << 5), a3 = rad[3] ^ (KKN << 5);
                     wn2_read<0>(raw[2], a2);
@@ -902,32 +915,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
                 }
                 w_piece(0);
                 if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(2);
-                wn2_mfma(acc[1][0], U[P][2], V[P][1]);
+                wn2_mfma<Z>(acc[1][0], U[P][2], V[P][1]);
                 wn2_read<SLN * WN_WSLOT + 0 * 4096 + 0>(U[Q][0], ubase);
                 wn2_read<SLN * WN_WSLOT + 0 * 4096 + 1024>(U[Q][1], ubase);
                 w_piece(1);
-                wn2_mfma(acc[1][1], U[P][3], V[P][1]);
+                wn2_mfma<Z>(acc[1][1], U[P][3], V[P][1]);
                 wn2_read<SLN * WN_WSLOT + 1 * 4096 + 0>(U[Q][2], ubase);
                 wn2_read<SLN * WN_WSLOT + 1 * 4096 + 1024>(U[Q][3], ubase);
                 if constexpr (HALF_DMA) w_piece(2);
                 x_piece(0);
                 if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(1);
-                wn2_mfma(acc[2][0], U[P][4], V[P][2]);
+                wn2_mfma<Z>(acc[2][0], U[P][4], V[P][2]);
                 wn2_read<SLN * WN_WSLOT + 2 * 4096 + 0>(U[Q][4], ubase);
                 wn2_read<SLN * WN_WSLOT + 2 * 4096 + 1024>(U[Q][5], ubase);
                 wn2_wait_lgkm<6>();                                            // the four raw fragments are in
                 if constexpr (HALF_DMA) w_piece(3);
                 V[Q][0] = wn2_sub(raw[0], raw[2]);                             // B^T d: V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
                 V[Q][1] = wn2_add(raw[1], raw[2]);
-                wn2_mfma(acc[2][1], U[P][5], V[P][2]);
+                wn2_mfma<Z>(acc[2][1], U[P][5], V[P][2]);
                 if constexpr (HALF_DMA) x_piece(1);
                 wn2_read<SLN * WN_WSLOT + 3 * 4096 + 0>(U[Q][6], ubase);
                 wn2_read<SLN * WN_WSLOT + 3 * 4096 + 1024>(U[Q][7], ubase);
                 V[Q][2] = wn2_sub(raw[2], raw[1]);
                 if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(0);
-                wn2_mfma(acc[3][0], U[P][6], V[P][3]);
+                wn2_mfma<Z>(acc[3][0], U[P][6], V[P][3]);
                 V[Q][3] = wn2_sub(raw[1], raw[3]);
-                wn2_mfma(acc[3][1], U[P][7], V[P][3]);
+                wn2_mfma<Z>(acc[3][1], U[P][7], V[P][3]);
                 if constexpr ((VAR & 2) && T == 6) { if (sample) wn2_clock<3>(clk); }          // end of sub-step 6
                 if constexpr ((VAR & 2) && T == 11) {
                     if (sample && lane < 8) reinterpret_cast<unsigned*>(p.stamps)[((long)blockIdx.x * 8 + wave) * 16 + lane] = clk;
@@ -938,7 +951,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             step(wn2_step_tag<8>{}); step(wn2_step_tag<9>{}); step(wn2_step_tag<10>{}); step(wn2_step_tag<11>{});
             wn2_wait_lgkm<0>();                // every request of the block has landed: the compiler may move the registers now
             xs ^= XSLOT;
-        }
+        };
+        block(0, wn2_true{});
+        for (int cb = 1; cb < cpt; ++cb) block(cb, wn2_false{});
 
         if constexpr (VAR & 64) { if (ct == t0) stamp(p.stamps, 4); }
         // the epilogue reads the accumulators with vector instructions: the last MFMAs must have left the matrix pipe (the
