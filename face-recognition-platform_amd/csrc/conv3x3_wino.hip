@@ -801,8 +801,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
     for (int ct = t0; ct < t1; ct += tstep) {
         // (flattened tiles: the accumulators are not cleared - the tile's first sub-step writes them with C = 0, wn2_mfma<true>: 128 v_mov
         // per wave and tile less, and with them gone the compiler moves the tile's address set-up into the first sub-step's gaps;
-        // in the 2-D form the same change made the allocator spill four registers and cost more than it saved)
-        if constexpr (T2D) {
+        // in the 2-D form the same change made the allocator spill four registers and cost more than it saved: 136 x 240 x 128
+        // 261-266 us with the clears, 275 with C = 0 (-DWN_T2D_C0=1))
+#ifndef WN_T2D_C0
+#define WN_T2D_C0 0
+#endif
+        if constexpr (T2D && !WN_T2D_C0) {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
             const bool sample = (VAR & 2) && p.stamps && blockIdx.x < 32 && ct == t0 && cb == (cpt > 1 ? 1 : 0);
             auto step = [&](auto tag) {
                 constexpr int T = decltype(tag)::value;
-                constexpr bool Z = FIRST_CB && T == 0 && !T2D;                  // the first MFMA into every accumulator of the tile
+                constexpr bool Z = FIRST_CB && T == 0 && (!T2D || WN_T2D_C0);                  // the first MFMA into every accumulator of the tile
                 constexpr int TN = (T + 1) % 12, KHN = TN / 4, KKN = TN % 4;
                 constexpr int P = T & 1, Q = P ^ 1;
                 constexpr int SLN = (T + 1) & 3;                               // ring slot of stage T + 1
