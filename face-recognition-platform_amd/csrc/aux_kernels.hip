@@ -373,4 +373,26 @@ hipError_t launch_fill_random_f16(_Float16* p, long n, unsigned seed, float scal
 }
 #endif  // FRP_LAB
 
+// Diagnostic (frp_debug_det_hashes, tools/det_hash_bisect.py): order-independent 64-bit hash of a tensor's 16-byte words, added to *slot.
+__global__ __launch_bounds__(256) void tensor_hash_kernel(const uint4* __restrict__ src, long n16, unsigned long long* __restrict__ slot) {
+    unsigned long long acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        unsigned long long a = ((unsigned long long)v.x << 32 | v.y) ^ 0x9e3779b97f4a7c15ull * (unsigned long long)(i + 1);
+        unsigned long long b = ((unsigned long long)v.z << 32 | v.w) + 0xc2b2ae3d27d4eb4full * (unsigned long long)(i + 1);
+        a ^= a >> 29; a *= 0xbf58476d1ce4e5b9ull; a ^= a >> 32;
+        b ^= b >> 31; b *= 0x94d049bb133111ebull; b ^= b >> 29;
+        acc += a + (b << 1 | b >> 63);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, acc);
+}
+hipError_t launch_tensor_hash(const void* src, size_t bytes, unsigned long long* slot, hipStream_t stream) {
+    const long n16 = (long)(bytes / 16);
+    if (n16 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tensor_hash_kernel, dim3(1024), dim3(256), 0, stream, (const uint4*)src, n16, slot);
+    return hipGetLastError();
+}
+
 }  // namespace frp

@@ -81,6 +81,9 @@ struct frp_handle {
     int dH = 0, dW = 0;              // dims of the detector source
     bool det_scaled = false;
     int canvas_h = 0, canvas_w = 0;
+    int det_op_limit = -1;           // >= 0: frp_debug_det_prefix - the detector program stops behind this many ops
+    DevBuf det_hashes;               // frp_debug_det_hashes: one 64-bit hash per detector op, taken right behind the op
+    bool det_hash_on = false;
     // per-call results (device)
     DevBuf boxes, kps, scores, counts, anchor, face_slot, nfaces, q16, part_cos, part_idx, best_cos, best_idx, scratch, splitk_ws, dense_logits;
     int fc_ksplit = 0;               // >0: the embedder's FC wrote split-K slabs; l2norm reduces them (-1: factor chosen on the device)
@@ -330,6 +333,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
     const char* wbase = (const char*)h->wdata.p;
     bool first = true;
     size_t skip = 0;
+    if (&net == &h->det && h->det_hash_on) HIPCHK(h, hipMemsetAsync(h->det_hashes.p, 0, 64 * 8, h->stream));
     // tile class of the conv launches (conv_common.h: conv_small_m): FRP_SMALL_M=0 never quarter tiles, =1 always, unset: by
     // the tile count of each launch (A/B runs, tests that pin a kernel family)
     const char* sm_env = getenv("FRP_SMALL_M");
@@ -353,6 +357,10 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         d[b.out_buf] = {sp.Ho2, sp.Wo2, 64, false};
         *flops += 2.0 * batch * sp.Ho1 * sp.Wo1 * 9.0 * 3 * 32 + 2.0 * batch * sp.Ho2 * sp.Wo2 * 9.0 * 32 * 64;
         *launches += 1;
+        if (h->det_hash_on) {
+            e = launch_tensor_hash(sp.out, (size_t)batch * sp.Ho2 * sp.Wo2 * 64 * 2, (unsigned long long*)h->det_hashes.p + 1, h->stream);
+            if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("tensor_hash: ") + hipGetErrorString(e));
+        }
         skip = 2;
         first = false;
     }
@@ -379,6 +387,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         }
     }
     for (const frp_conv_op& op : net.ops) {
+        if (&net == &h->det && h->det_op_limit >= 0 && (int)(&op - net.ops.data()) >= h->det_op_limit) break;   // (diagnostic prefix run)
         if (skip) { --skip; continue; }
         if (first && stem) {
             first = false;
@@ -491,6 +500,11 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         out.f8 = (op.flags & FRP_OPFLAG_OUT_FP8) != 0;
         d[op.out_buf] = out;
         if (op.out2_buf >= 0) { TensorDims o2 = out; o2.f8 = true; d[op.out2_buf] = o2; }
+        if (&net == &h->det && h->det_hash_on && opi < 64 && !n_dev) {      // (diagnostic: hash of this op's output, in stream order)
+            e = launch_tensor_hash(net.bufs[op.out_buf].p, (size_t)batch * out.h * out.w * out.c * (out.f32 ? 4 : 2),
+                                   (unsigned long long*)h->det_hashes.p + opi, h->stream);
+            if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("tensor_hash: ") + hipGetErrorString(e));
+        }
         const int cin_r = op.real_ch & 0xffff, cout_r = (op.real_ch >> 16) & 0xffff;
         const double fl = 2.0 * batch * out.h * out.w * (double)op.ksize * op.ksize * (cin_r ? cin_r : op.cin) * (cout_r ? cout_r : op.cout);
         *flops += fl;
@@ -1052,7 +1066,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
                      &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery,
-                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes};
+                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes, &h->det_hashes};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i) {
@@ -1746,6 +1760,62 @@ int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_by
     if (!out_f16) return FRP_OK;
     if (out_bytes < need) return fail(h, FRP_ERR_INVALID, "head map buffer too small");
     HIPCHK(h, hipMemcpyAsync(out_f16, h->det.bufs[bi].p, (size_t)need, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return FRP_OK;
+}
+
+// Diagnostic (tools/det_hash_bisect.py): enable != 0 - every later detector pass takes a 64-bit hash of each op's output right behind
+// the op (stream order: the tensor as the NEXT op reads it); out64 (64 slots, op order) receives the hashes of the last pass.
+int frp_debug_det_hashes(frp_handle* h, int32_t enable, uint64_t* out64) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (enable) {
+        FRPCHK(ensure(h, h->det_hashes, 64 * 8));
+        h->det_hash_on = true;
+    } else h->det_hash_on = false;
+    if (out64) {
+        if (!h->det_hashes.p) return fail(h, FRP_ERR_INVALID, "hashes were never enabled");
+        HIPCHK(h, hipMemcpyAsync(out64, h->det_hashes.p, 64 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return FRP_OK;
+}
+
+// Diagnostic (tools/det_bisect.py): the detector program on the resident frames up to and including op `n_ops - 1`, then that op's
+// output tensor [B, th, tw, tc] fp16.  Physical buffers are shared between tensors by liveness, so a tensor can only be read
+// while nothing behind it has run: hence a prefix run rather than a read after a full pass.
+int frp_debug_det_prefix(frp_handle* h, int32_t n_ops, void* out_f16, int64_t out_bytes, int32_t* th, int32_t* tw, int32_t* tc) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->have_weights) return fail(h, FRP_ERR_NO_WEIGHTS, "no weights loaded");
+    if (h->rB <= 0) return fail(h, FRP_ERR_INVALID, "no resident frames (call frp_upload_frames)");
+    if (n_ops <= 0 || n_ops > (int)h->det.ops.size()) return fail(h, FRP_ERR_INVALID, "op count out of range");
+    const int B = h->rB, Hc = h->canvas_h, Wc = h->canvas_w;
+    const bool fused = stem_fusable(h->det) && !getenv("FRP_NO_FUSED_STEM");
+    if (!fused) return fail(h, FRP_ERR_INVALID, "prefix runs need the fused stem");
+    FRPCHK(plan_net(h, h->det, B, Hc, Wc, fused));
+    StemParams sp{};
+    sp.frames = h->det_scaled ? (const uint8_t*)h->scaled.p : (const uint8_t*)h->frames.p;
+    sp.B = B; sp.H = h->dH; sp.W = h->dW;
+    sp.row_stride = (long)h->dW * 3; sp.frame_stride = (long)h->dH * h->dW * 3;
+    sp.Hc = Hc; sp.Wc = Wc; sp.Ho = Hc / 2; sp.Wo = Wc / 2;
+    sp.rgb_in = 0;
+    const bool det_wino = (long)B * (Hc / 8) * (Wc / 8) >= 2L * 240 * (h->n_cu > 0 ? h->n_cu : 256);
+    double fl = 0.0;
+    int64_t ln = 0;
+    h->det_op_limit = n_ops;
+    const int rc = run_net(h, h->det, B, Hc, Wc, &fl, &ln, &sp, nullptr, det_wino);
+    h->det_op_limit = -1;
+    if (rc != FRP_OK) return rc;
+    const frp_conv_op& op = h->det.ops[n_ops - 1];
+    const TensorDims d = h->det.dims[op.out_buf];
+    if (th) *th = d.h;
+    if (tw) *tw = d.w;
+    if (tc) *tc = d.c;
+    const int64_t need = (int64_t)B * d.h * d.w * d.c * 2;
+    if (!out_f16) { HIPCHK(h, hipStreamSynchronize(h->stream)); return FRP_OK; }
+    if (out_bytes < need) return fail(h, FRP_ERR_INVALID, "tensor buffer too small");
+    HIPCHK(h, hipMemcpyAsync(out_f16, h->det.bufs[op.out_buf].p, (size_t)need, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return FRP_OK;
 }

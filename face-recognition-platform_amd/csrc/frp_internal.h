@@ -156,6 +156,7 @@ struct JpegParams {
 hipError_t launch_jpeg_decode(const JpegParams& p, hipStream_t stream);
 
 // u8 bilinear resize for the detection pyramid (frames [B,H,W,3] tightly packed)
+hipError_t launch_tensor_hash(const void* src, size_t bytes, unsigned long long* slot, hipStream_t stream);
 hipError_t launch_resize_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int Hs, int Ws, hipStream_t stream);
 
 // K4: 5-point similarity + bilinear warp to 112x112 -> normalised fp16 NHWC8 chips

@@ -217,6 +217,12 @@ __global__ __launch_bounds__(256, 2) void stem12_u8_kernel(Stem12Params p) {
     // every halfword of the patch is finite from the start: the windows of the last columns read row tails (and 8
     // halfwords past the last row) that meet zero weights, and 0 x NaN would not be 0
     for (int e = t; e < S12_PATCH_HALFS; e += 256) patch[e] = (_Float16)0.f;
+    // ... and the fill is complete before ANY wave stages the first tile: the fill and phase A map threads to patch elements
+    // differently, so without this barrier a wave that starts late zeroes halfwords another wave has already staged (round 5:
+    // one 4 x 32 tile among the first tiles of the workgroups off by a few per cent once in ~350 passes of 4 x 1080p, whatever
+    // kernel family followed - found by tools/det_hash_bisect.py; the cross-family test of round 4 was the first one tight
+    // enough to see it)
+    __syncthreads();
 
     // The u8 patch of a tile is fetched as aligned dwords (99 per patch row, 8 per thread) one tile AHEAD:
     // the loads are issued before phase B of the previous tile and unpacked in phase A, so their HBM

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
-    "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
+    "frp_detect", "frp_detect_resident", "frp_get_det_source", "frp_finish_faces", "frp_get_head_map", "frp_debug_det_prefix", "frp_debug_det_hashes", "frp_decode_heads", "frp_align", "frp_embed_aligned", "frp_embed_faces",
     "frp_match", "frp_match_scores", "frp_conv2d_nhwc", "frp_conv2d_f8", "frp_get_counters", "frp_reset_counters", "frp_set_profile",
 ]
 
@@ -182,6 +182,8 @@ def load_library() -> C.CDLL:
     lib.frp_get_det_source.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.frp_finish_faces.argtypes = [vp, i32, vp, vp, vp, vp, i32, u32, vp, vp, vp]
     lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.frp_debug_det_prefix.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.frp_debug_det_hashes.argtypes = [vp, i32, vp]
     lib.frp_decode_heads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
     lib.frp_align.argtypes = [vp, vp, i32, i32, i64, vp, i32, u32, vp]
     lib.frp_embed_aligned.argtypes = [vp, vp, i32, vp]
@@ -490,6 +492,20 @@ class Engine:
             self._chk(self._lib.frp_get_head_map(self._h, lv, _ptr(a), a.nbytes, C.byref(hl), C.byref(wl)))
             outs.append(a)
         return outs
+
+    def det_prefix(self, n_ops: int) -> np.ndarray:
+        """diagnostic: the detector on the RESIDENT frames up to and including op n_ops - 1; that op's output [B,h,w,c] fp16"""
+        th, tw, tc = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._lib.frp_debug_det_prefix(self._h, n_ops, None, 0, C.byref(th), C.byref(tw), C.byref(tc)))
+        a = np.empty((self._resident[0], th.value, tw.value, tc.value), dtype=np.float16)
+        self._chk(self._lib.frp_debug_det_prefix(self._h, n_ops, _ptr(a), a.nbytes, C.byref(th), C.byref(tw), C.byref(tc)))
+        return a
+
+    def det_hashes(self, enable: bool = True, fetch: bool = True):
+        """diagnostic: per-op output hashes of the last detector pass (uint64[64]); enable keeps them on for later passes"""
+        out = np.zeros(64, np.uint64) if fetch else None
+        self._chk(self._lib.frp_debug_det_hashes(self._h, 1 if enable else 0, _ptr(out) if fetch else None))
+        return out
 
     def decode_heads(self, heads, canvas_hw, max_faces=10, det_thresh=0.5, nms_iou=0.4, flags=0):
         hs = [np.ascontiguousarray(x, dtype=np.float16) for x in heads]

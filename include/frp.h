@@ -227,6 +227,13 @@ int frp_finish_faces(frp_handle* h, int32_t B, const float* boxes, const float* 
 /* raw detector head maps of the last detect/process call, per stride level 0..2:
  * [B, H/stride, W/stride, 32] fp16 (parity tests) */
 int frp_get_head_map(frp_handle* h, int32_t level, void* out_f16, int64_t out_bytes, int32_t* hl, int32_t* wl);
+/* diagnostic: runs the detector program on the resident frames up to and including op n_ops - 1 and returns that op's
+ * output [B, th, tw, tc] fp16 (out_f16 NULL: dimensions only, the prefix still runs).  Buffers are shared between tensors,
+ * so an inner tensor is only readable from a prefix run (tools/det_bisect.py: per-layer determinism / parity bisection) */
+int frp_debug_det_prefix(frp_handle* h, int32_t n_ops, void* out_f16, int64_t out_bytes, int32_t* th, int32_t* tw, int32_t* tc);
+/* diagnostic: enable != 0 - every later detector pass hashes each op's output right behind the op (one 64-bit slot per op,
+ * 64 slots); out64 != NULL receives the hashes of the last pass (tools/det_hash_bisect.py: which op of a FULL pass differed) */
+int frp_debug_det_hashes(frp_handle* h, int32_t enable, uint64_t* out64);
 /* decode + NMS on caller-supplied head maps [B,H_l,W_l,32] fp16 (parity tests) */
 int frp_decode_heads(frp_handle* h, const void* head8, const void* head16, const void* head32,
                      int32_t B, int32_t canvas_h, int32_t canvas_w, int32_t max_faces, float det_thresh, float nms_iou,
