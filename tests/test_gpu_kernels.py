@@ -98,6 +98,7 @@ def test_conv_parity(engine, case, tiles):
     assert err <= tol, f"max err {err} > {tol}"
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and c[3] % 64 == 0])
 def test_conv_row_patch_kernel_equals_generic_kernel(engine, case):
     """conv3x3_rows.hip and conv_mfma.hip accumulate in the same k order -> identical bits."""
@@ -326,6 +327,7 @@ def test_align_parity(engine):
     assert err.mean() < 5e-4
 
 
+@pytest.mark.selfcheck
 def test_embedder_stem_kernel_agrees_with_generic_conv(engine, monkeypatch):
     """emb_stem_kernel vs the generic small-Cin conv path on the same chips: same fp16 inputs, fp32
     accumulation in a different order -> embeddings equal to ~1e-4"""
@@ -464,6 +466,7 @@ def test_decode_threshold_one_ulp_and_exact_iou_tie(engine):
     assert np.array_equal(ob[0], np.array([0, 0, 9, 13], np.float32))
 
 
+@pytest.mark.selfcheck
 def test_fused_stems_agree_with_the_two_kernel_path(engine, monkeypatch):
     """stem12_u8_kernel vs stem_u8_kernel + generic conv: same fp16 stem1 values, fp32 accumulation in a
     different order -> head maps equal up to fp16 rounding noise; BGR and RGB inputs give the same result"""
@@ -515,6 +518,7 @@ def test_match_topk_parity(engine, N, M, k):
         assert list(idx[0, :3]) == [3, 700, 701]
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("N,M", [(1, 1), (31, 5), (1000, 33), (4097, 320), (70001, 512), (300, 513)])
 def test_match_running_best_kernel_equals_per_tile_kernel(engine, monkeypatch, N, M):
     """the persistent top-1 kernel (running winners in registers, M <= 512) and the per-tile kernel (FRP_MATCH_V1=1; also
@@ -699,6 +703,7 @@ def test_conv_winograd_2d_tiles_parity(engine, case):
         engine.conv2d(x[:1], w, bias, stride=1, act=act, slope=slope, res=None if res is None else res[:1], flags=flags | 0x10000)
 
 
+@pytest.mark.selfcheck
 def test_conv_winograd_ring_stress(engine):
     """The Winograd kernel's rings under timing pressure (round 4: the weight ring runs three sub-steps ahead and a slot is
     restaged by the sub-step that computes on the fragments read from it; round 3's review: no stress configuration of its
