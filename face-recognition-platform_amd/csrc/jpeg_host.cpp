@@ -11,6 +11,7 @@
 // components.  Progressive / arithmetic / 12-bit / multi-scan files are reported as unsupported (FRP_ERR_INVALID), never
 // half-decoded.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -110,6 +111,9 @@ struct BitReader {
     uint64_t acc = 0;
     int nbits = 0;
     bool hit_marker = false;      // a marker (other than stuffing) was reached: only zero bits are fed from here on
+    int pad_bits = 0;             // zero bits fed behind a marker / the end of the data (still in the window, or consumed)
+    // true when the decoder has consumed bits that were not in the file (the window holds fewer bits than were padded in)
+    bool ran_dry() const { return nbits < pad_bits; }
     void fill_slow() {
         while (nbits <= 56) {
             uint32_t b = 0;
@@ -124,6 +128,7 @@ struct BitReader {
             } else {
                 hit_marker = true;
             }
+            if (hit_marker) pad_bits += 8;
             acc |= (uint64_t)b << (56 - nbits);
             nbits += 8;
         }
@@ -166,7 +171,7 @@ struct BitReader {
         }
         return -1;
     }
-    void reset_at(const uint8_t* q) { p = q; acc = 0; nbits = 0; hit_marker = false; }
+    void reset_at(const uint8_t* q) { p = q; acc = 0; nbits = 0; hit_marker = false; pad_bits = 0; }
 };
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -183,6 +188,18 @@ struct JpegHeaderInternal {
     std::string err;
 };
 
+// Largest image (width x height) the decoder accepts: the SOF dimensions come from untrusted bytes and size every buffer
+// behind them (a 200-byte file can claim 65,535 x 65,535).  Default = PIL's Image.MAX_IMAGE_PIXELS (the reference decodes
+// uploads with PIL, face_service.py:139); FRP_JPEG_MAX_PIXELS overrides it (read once).
+long long jpeg_max_pixels() {
+    static const long long lim = [] {
+        const char* e = getenv("FRP_JPEG_MAX_PIXELS");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 89478485LL;
+    }();
+    return lim;
+}
+
 static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
     if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) { H.err = "not a JPEG (no SOI)"; return FRP_ERR_INVALID; }
     build_table(H.dc[0], kStdDcLumaBits, kStdDcVals, 12);                  // Annex K defaults; a DHT segment replaces them
@@ -190,7 +207,8 @@ static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
     build_table(H.ac[0], kStdAcLumaBits, kStdAcLumaVals, 162);
     build_table(H.ac[1], kStdAcChromaBits, kStdAcChromaVals, 162);
     size_t pos = 2;
-    bool have_sof = false;
+    bool have_sof = false, saw_jfif = false, saw_adobe = false;
+    int adobe_transform = 0;
     frp_jpeg_info& I = H.info;
     while (pos + 4 <= n) {
         if (d[pos] != 0xFF) { H.err = "marker expected"; return FRP_ERR_INVALID; }
@@ -255,6 +273,7 @@ static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
                 return FRP_ERR_INVALID;
             }
             if (I.components == 1) { I.h_samp[0] = I.v_samp[0] = 1; hmax = vmax = 1; }     // a single component is never interleaved
+            if ((long long)I.width * I.height > jpeg_max_pixels()) { H.err = "image exceeds the pixel limit (FRP_JPEG_MAX_PIXELS)"; return FRP_ERR_INVALID; }
             I.mcus_x = (I.width + 8 * hmax - 1) / (8 * hmax);
             I.mcus_y = (I.height + 8 * vmax - 1) / (8 * vmax);
             have_sof = true;
@@ -262,11 +281,16 @@ static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
             H.err = "progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)";
             I.progressive = 1;
             return FRP_ERR_INVALID;
+        } else if (m == 0xE0) {                                       // APP0: JFIF fixes the colour space (YCbCr / grey)
+            if (sl >= 5 && memcmp(s, "JFIF\0", 5) == 0) saw_jfif = true;
+        } else if (m == 0xEE) {                                       // APP14: Adobe transform flag (0 = RGB / CMYK as stored, 1 = YCbCr)
+            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0) { saw_adobe = true; adobe_transform = s[11]; }
         } else if (m == 0xDD) {                                       // DRI
             if (sl < 2) { H.err = "bad DRI"; return FRP_ERR_INVALID; }
             I.restart_interval = be16(s);
         } else if (m == 0xDA) {                                       // SOS
             if (!have_sof) { H.err = "SOS before SOF"; return FRP_ERR_INVALID; }
+            if (sl < 1) { H.err = "bad SOS"; return FRP_ERR_INVALID; }
             const int ns = s[0];
             if (ns != I.components || sl < 1 + 2 * ns + 3) { H.err = "multi-scan files are not supported"; return FRP_ERR_INVALID; }
             for (int c = 0; c < ns; ++c) {
@@ -277,6 +301,13 @@ static int parse_headers(const uint8_t* d, size_t n, JpegHeaderInternal& H) {
                     H.err = "scan refers to a table the file does not define";
                     return FRP_ERR_INVALID;
                 }
+            }
+            // colour space of a 3-component file as libjpeg decides it (jdapimin.c: default_decompress_parms), which PIL - the
+            // reference's decoder - follows: JFIF -> YCbCr; else Adobe transform 0 -> RGB; else component ids 'R','G','B' -> RGB.
+            // The device path converts YCbCr only: RGB-stored files are reported unsupported and take the host decoder.
+            if (I.components == 3 && !saw_jfif) {
+                const bool rgb_ids = H.comp_id[0] == 'R' && H.comp_id[1] == 'G' && H.comp_id[2] == 'B';
+                if (saw_adobe ? adobe_transform == 0 : rgb_ids) { H.err = "RGB-stored JPEG (Adobe transform 0 / RGB component ids) is not supported"; return FRP_ERR_INVALID; }
             }
             if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63) { H.err = "spectral selection is not supported (baseline only)"; return FRP_ERR_INVALID; }
             H.scan = d + pos + len;
@@ -332,6 +363,7 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
         for (int mx = 0; mx < I.mcus_x; ++mx) {
             if (I.restart_interval && restart_left == 0) {
                 // byte-align, expect RSTn
+                if (br.ran_dry()) { if (err) *err = "entropy-coded data ends before the restart interval is complete"; return FRP_ERR_INVALID; }
                 const uint8_t* q = br.p;
                 while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;       // (br.p sits at or before the marker)
                 if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) { if (err) *err = "restart marker missing or out of sequence"; return FRP_ERR_INVALID; }
@@ -378,6 +410,10 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
             }
             if (I.restart_interval) --restart_left;
         }
+    // Bits that were not in the file were consumed: the scan ends (end of data, or a marker) before its last MCU.  libjpeg pads
+    // such a scan with a warning and PIL raises "image file is truncated"; here it is an error, so the caller's host path
+    // (PIL) decides - never a silently grey frame.
+    if (br.ran_dry()) { if (err) *err = "entropy-coded data ends before the last MCU (truncated file)"; return FRP_ERR_INVALID; }
     return FRP_OK;
 }
 

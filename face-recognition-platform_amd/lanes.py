@@ -176,7 +176,11 @@ def run_ordered(batches: Iterable[Any], workers: Sequence[Callable[..., Any]], p
             cv.notify_all()
         for th in threads:
             th.join()
-        feed.join(timeout=0.2)           # a feeder parked inside a live source leaves with that source's next item (daemon)
+        # The feeder may be parked inside the source's `next()` (a live camera that has no frame yet): it is a daemon thread and
+        # leaves with the source's next item or its end.  Until then the SOURCE ITERATOR IS STILL IN USE by that thread - a caller
+        # that abandons the results early must not reuse or close a generator source before it has produced once more
+        # ("generator already executing"); sources with a close() of their own (MjpegCapture.release, StreamMixer.close) end it.
+        feed.join(timeout=0.2)
 
 
 class Lanes:

@@ -54,10 +54,16 @@ class JpegBatch(list):
         return out
 
 
+# Sizes taken from a stream (Content-Length, AVI chunk sizes) and frames that never end are bounded by this: a larger frame is
+# dropped and the demuxer looks for the next start-of-image (a 4K 4:4:4 JPEG at quality 100 is ~25 MB).
+MAX_FRAME_BYTES = 32 << 20
+
 # ---------------------------------------------------------------------------------------------- finding frames in a byte stream
 
-def jpeg_end(buf: Union[bytes, bytearray], start: int = 0) -> Optional[int]:
+def jpeg_end(buf: Union[bytes, bytearray], start: int = 0, state: Optional[list] = None) -> Optional[int]:
     """`buf[start:]` begins with SOI: -> index one past this JPEG's EOI, or None while the frame is still incomplete.
+    `state` (a list owned by the caller, [] for a new frame): where the walk stopped, so that the next call - same frame, more
+    bytes - continues there instead of walking the frame from its start again (a 25 MB frame arriving in 64 KiB chunks).
     Walks the marker segments by their lengths (an EXIF thumbnail inside APP1 carries its own SOI / EOI and must not end the
     frame) and scans only entropy-coded data for the next marker (0xFF followed by anything but 0x00 / RSTn)."""
     n = len(buf)
@@ -65,16 +71,37 @@ def jpeg_end(buf: Union[bytes, bytearray], start: int = 0) -> Optional[int]:
         return None
     if buf[start] != 0xFF or buf[start + 1] != 0xD8:
         raise ValueError("not at a JPEG start-of-image marker")
-    i = start + 2
+    i, in_scan = (state[0], state[1]) if state else (start + 2, False)
+
+    def parked(pos, scanning):
+        if state is not None:
+            state[:] = [pos, scanning]
+        return None
     while True:
+        if in_scan:                                # (resumed inside entropy-coded data)
+            in_scan = False
+            while True:
+                j = buf.find(b"\xff", i)
+                if j < 0 or j + 1 >= n:
+                    return parked(max(i, n - 1) if j < 0 else j, True)
+                nxt = buf[j + 1]
+                if nxt == 0x00 or 0xD0 <= nxt <= 0xD7:
+                    i = j + 2
+                elif nxt == 0xFF:
+                    i = j + 1
+                else:
+                    i = j
+                    break
+            continue
         if i + 2 > n:
-            return None
+            return parked(i, False)
         if buf[i] != 0xFF:
             raise ValueError("corrupt JPEG: marker expected")
+        i0 = i
         while i < n and buf[i] == 0xFF:            # fill bytes
             i += 1
         if i >= n:
-            return None
+            return parked(i0, False)
         m = buf[i]
         i += 1
         if m == 0xD9:
@@ -84,50 +111,48 @@ def jpeg_end(buf: Union[bytes, bytearray], start: int = 0) -> Optional[int]:
         if m == 0x01 or 0xD0 <= m <= 0xD7:
             continue
         if i + 2 > n:
-            return None
+            return parked(i0, False)
         seg = (buf[i] << 8) | buf[i + 1]
         if seg < 2:
             raise ValueError("corrupt JPEG: segment length")
+        if i + seg > n:
+            return parked(i0, False)
         i += seg
-        if i > n:
-            return None
         if m == 0xDA:                              # entropy-coded data up to the next real marker
-            while True:
-                j = buf.find(b"\xff", i)
-                if j < 0 or j + 1 >= n:
-                    return None
-                nxt = buf[j + 1]
-                if nxt == 0x00 or 0xD0 <= nxt <= 0xD7:
-                    i = j + 2
-                elif nxt == 0xFF:
-                    i = j + 1
-                else:
-                    i = j
-                    break
+            in_scan = True
 
 
-def split_stream(chunks: Iterable[bytes]) -> Iterator[JpegFrame]:
+def split_stream(chunks: Iterable[bytes], max_frame_bytes: int = MAX_FRAME_BYTES) -> Iterator[JpegFrame]:
     """byte chunks of back-to-back JPEG frames (a raw .mjpeg file, a camera pipe; bytes between frames - multipart headers,
-    padding - are skipped) -> complete frames.  A damaged frame is dropped at the next start-of-image."""
+    padding - are skipped) -> complete frames.  A damaged frame - or one that has not ended after `max_frame_bytes` - is
+    dropped at the next start-of-image; the buffer never holds more than one such frame plus a chunk."""
     buf = bytearray()
+    state: list = []                               # where jpeg_end stopped in the frame at buf[0]
     for chunk in chunks:
         if not chunk:
             continue
         buf += chunk
         while True:
-            s = buf.find(b"\xff\xd8\xff")
-            if s < 0:
-                del buf[:max(0, len(buf) - 2)]
-                break
-            if s:
-                del buf[:s]
+            if not state:
+                s = buf.find(b"\xff\xd8\xff")
+                if s < 0:
+                    del buf[:max(0, len(buf) - 2)]
+                    break
+                if s:
+                    del buf[:s]
             try:
-                e = jpeg_end(buf, 0)
+                e = jpeg_end(buf, 0, state)
             except ValueError:
                 del buf[:2]                        # not a frame after all: look for the next SOI
+                state.clear()
                 continue
             if e is None:
+                if len(buf) > max_frame_bytes:     # no end in sight: drop it, resynchronise
+                    del buf[:2]
+                    state.clear()
+                    continue
                 break
+            state.clear()
             yield JpegFrame(bytes(buf[:e]))
             del buf[:e]
 
@@ -140,9 +165,11 @@ def _chunks(fp: BinaryIO, size: int = 1 << 16) -> Iterator[bytes]:
         yield b
 
 
-def multipart_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
+def multipart_frames(fp: BinaryIO, max_frame_bytes: int = MAX_FRAME_BYTES) -> Iterator[JpegFrame]:
     """body of an HTTP `multipart/x-mixed-replace` response (IP cameras): parts with a Content-Length are cut by it, parts
-    without one by the JPEG's own end-of-image; anything that is not a JPEG part is skipped"""
+    without one by the JPEG's own end-of-image; anything that is not a JPEG part is skipped.  A Content-Length that is negative
+    or larger than `max_frame_bytes` is not believed (the part is then cut by its markers), and a part without an end is dropped
+    once it has grown past that size"""
     buf = bytearray()
     eof = False
 
@@ -177,6 +204,8 @@ def multipart_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
                         length = int(v.strip())
                     except ValueError:
                         length = None
+                    if length is not None and not (0 < length <= max_frame_bytes):
+                        length = None
             del buf[:h + 4]
         if length is not None:
             if not need(length):
@@ -187,22 +216,30 @@ def multipart_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
                 yield JpegFrame(part)
             continue
         # no length: the frame ends at its own EOI
+        state: list = []
         while True:
-            s = buf.find(b"\xff\xd8\xff")
-            if s < 0:
-                if not need(len(buf) + 1):
-                    return
-                continue
-            del buf[:s]
+            if not state:
+                s = buf.find(b"\xff\xd8\xff")
+                if s < 0:
+                    del buf[:max(0, len(buf) - 2)]
+                    if not need(len(buf) + 1):
+                        return
+                    continue
+                del buf[:s]
             try:
-                e = jpeg_end(buf, 0)
+                e = jpeg_end(buf, 0, state)
             except ValueError:
                 del buf[:2]
+                state.clear()
                 continue
             if e is not None:
                 yield JpegFrame(bytes(buf[:e]))
                 del buf[:e]
                 break
+            if len(buf) > max_frame_bytes:         # no end in sight: drop it, resynchronise
+                del buf[:2]
+                state.clear()
+                continue
             if not need(len(buf) + 1):
                 return
 
@@ -220,10 +257,11 @@ def _skip(fp: Any, n: int) -> None:
             n -= len(got)
 
 
-def avi_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
+def avi_frames(fp: BinaryIO, max_frame_bytes: int = MAX_FRAME_BYTES) -> Iterator[JpegFrame]:
     """video chunks ('..dc' / '..db') of the first MJPG stream of a RIFF/AVI file, in file order (the lists that hold chunks -
     hdrl, strl, movi, rec - are walked through, everything else is skipped by its length; no index is needed).  Raises
-    ValueError for a file that is not an AVI or whose video stream is not Motion-JPEG."""
+    ValueError for a file that is not an AVI or whose video stream is not Motion-JPEG.  Chunk sizes come from the file: a video
+    chunk larger than `max_frame_bytes` is skipped, a stream header is read up to 64 KiB."""
     head = fp.read(12)
     if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"AVI ":
         raise ValueError("not a RIFF/AVI file")
@@ -241,7 +279,8 @@ def avi_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
         elif cid == b"RIFF":                       # OpenDML continuation ('AVIX'): more movi lists
             fp.read(4)
         elif cid == b"strh":
-            data = fp.read(size + (size & 1))
+            data = fp.read(min(size, 1 << 16))
+            _skip(fp, size + (size & 1) - len(data))
             if data[:4] == b"vids" and video_stream is None:
                 fourcc = data[4:8].upper()
                 if fourcc not in (b"MJPG", b"JPEG", b"AVRN", b"LJPG", b"\0\0\0\0"):
@@ -249,6 +288,9 @@ def avi_frames(fp: BinaryIO) -> Iterator[JpegFrame]:
                 video_stream = n_streams
             n_streams += 1
         elif cid[2:] in (b"dc", b"db") and cid[:2].isdigit():
+            if size > max_frame_bytes:
+                _skip(fp, size + (size & 1))
+                continue
             data = fp.read(size + (size & 1))
             if (video_stream is None or int(cid[:2]) == video_stream) and data[:3] == b"\xff\xd8\xff":
                 yield JpegFrame(data[:size])

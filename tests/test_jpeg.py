@@ -118,10 +118,99 @@ def test_files_outside_the_decoders_scope_are_refused_not_half_decoded():
     assert native.jpeg_info(good[:60]) is None                             # truncated inside the headers
     with pytest.raises(native.FrpError):
         native.jpeg_coefficients(good[:20])
-    # a scan cut short decodes to zeros behind the cut (no crash, no read past the buffer); a corrupt table is an error
-    info, coef, q = native.jpeg_coefficients(good[: len(good) * 2 // 3] + b"\xff\xd9")
-    assert info["width"] > 0 and coef.shape[0] > 0
+    # a scan cut short is an ERROR (PIL: "image file is truncated"), not a frame that turns grey behind the cut; a file that
+    # only lacks its EOI marker has every MCU and decodes
+    with pytest.raises(native.FrpError):
+        native.jpeg_coefficients(good[: len(good) * 2 // 3] + b"\xff\xd9")
+    with pytest.raises(native.FrpError):
+        native.jpeg_coefficients(good[: len(good) * 2 // 3])
+    assert good.endswith(b"\xff\xd9")
+    info, coef, q = native.jpeg_coefficients(good[:-2])
+    info_f, coef_f, _ = native.jpeg_coefficients(good)
+    assert info == info_f and np.array_equal(coef, coef_f)
     bad = bytearray(good)
     i = bad.find(b"\xff\xc4")
     bad[i + 5:i + 21] = b"\xff" * 16                                       # an over-subscribed Huffman table
     assert native.jpeg_info(bytes(bad)) is None
+
+
+def test_truncation_inside_a_restart_interval_is_an_error_too():
+    good = open(os.path.join(HERE, "golden", "stills", "c420_rst_q90.jpg"), "rb").read()
+    sos = good.find(b"\xff\xda")
+    rst = [i for i in range(sos, len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(rst) >= 3
+    # half of the second interval's bytes removed: the interval ends (at its RST marker) before its MCUs are complete
+    a, b = rst[0] + 2, rst[1]
+    cut = good[:a + (b - a) // 2] + good[b:]
+    with pytest.raises(native.FrpError):
+        native.jpeg_coefficients(cut)
+
+
+def _sof_patched(data: bytes, h: int, w: int) -> bytes:
+    i = data.find(b"\xff\xc0")
+    return data[:i + 5] + bytes([h >> 8, h & 255, w >> 8, w & 255]) + data[i + 9:]
+
+
+def test_dimensions_from_untrusted_bytes_are_capped_before_anything_is_sized(monkeypatch):
+    """round 4's advice: a ~200-byte header claiming 65,535 x 65,535 sized a 12.9 GB page-locked buffer and 32 GB of device
+    buffers.  The limit is PIL's Image.MAX_IMAGE_PIXELS (89,478,485; FRP_JPEG_MAX_PIXELS overrides it)."""
+    good = open(STILLS[0], "rb").read()
+    huge = _sof_patched(good, 65535, 65535)
+    assert native.jpeg_info(huge) is None
+    with pytest.raises(native.FrpError):
+        native.jpeg_coefficients(huge)
+    assert native.jpeg_info(_sof_patched(good, 9459, 9459)) is not None      # 89,472,681 pixels: just inside
+    assert native.jpeg_info(_sof_patched(good, 9460, 9460)) is None          # 89,491,600: outside
+    assert Image.MAX_IMAGE_PIXELS == 89478485
+
+
+def test_sos_segment_at_the_very_end_of_the_buffer():
+    """round 4's advice: `FF DA 00 02` as the file's last bytes made the parser read the component count one byte past the buffer"""
+    good = open(STILLS[0], "rb").read()
+    sos = good.find(b"\xff\xda")
+    assert native.jpeg_info(good[:sos] + b"\xff\xda\x00\x02") is None
+    assert native.jpeg_info(good[:sos] + b"\xff\xda\x00\x03\x03") is None
+
+
+def _with_adobe_marker(data: bytes, transform: int, keep_jfif: bool) -> bytes:
+    """the same entropy-coded data behind an APP14 'Adobe' segment (and, optionally, without its JFIF APP0)"""
+    out, i = bytearray(data[:2]), 2
+    adobe = b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00" + bytes([transform])
+    out += adobe
+    while True:
+        m, L = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == 0xDA:
+            return bytes(out + data[i:])
+        if not (m == 0xE0 and not keep_jfif):
+            out += data[i:i + 2 + L]
+        i += 2 + L
+
+
+def test_rgb_stored_files_take_the_host_decoder():
+    """round 4's advice: libjpeg (PIL) treats a 3-component file without a JFIF marker as RGB when its Adobe marker says
+    transform 0, or when its component ids are 'R','G','B'; the device path converts YCbCr only and must not claim such files"""
+    p444 = [p for p in STILLS if "444" in os.path.basename(p)][0]
+    ycc = open(p444, "rb").read()
+    rgb_stored = _with_adobe_marker(ycc, 0, keep_jfif=False)
+    assert not np.array_equal(_pil_rgb(rgb_stored), _pil_rgb(ycc))            # PIL does read it as RGB: other pixels from the same bits
+    assert native.jpeg_info(rgb_stored) is None
+    with pytest.raises(native.FrpError):
+        native.jpeg_coefficients(rgb_stored)
+    # transform 1 (YCbCr), and transform 0 next to a JFIF marker (JFIF wins in libjpeg): still ours, and still PIL's pixels
+    for variant in (_with_adobe_marker(ycc, 1, keep_jfif=False), _with_adobe_marker(ycc, 0, keep_jfif=True)):
+        assert np.array_equal(_pil_rgb(variant), _pil_rgb(ycc))
+        info, coef, q = native.jpeg_coefficients(variant)
+        assert np.array_equal(oj.decode_from_coefficients(info, coef, q), _pil_rgb(ycc))
+    # component ids 'R','G','B' without any marker
+    i = ycc.find(b"\xff\xc0")
+    ids = bytearray(_with_adobe_marker(ycc, 1, keep_jfif=False).replace(b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x01", b""))
+    i = ids.find(b"\xff\xc0")
+    old = [ids[i + 10 + 3 * c] for c in range(3)]
+    for c, ch in enumerate(b"RGB"):
+        ids[i + 10 + 3 * c] = ch
+    j = ids.find(b"\xff\xda")
+    for c, ch in enumerate(b"RGB"):
+        assert ids[j + 5 + 2 * c] == old[c]
+        ids[j + 5 + 2 * c] = ch
+    assert not np.array_equal(_pil_rgb(bytes(ids)), _pil_rgb(ycc))
+    assert native.jpeg_info(bytes(ids)) is None

@@ -174,3 +174,53 @@ def test_encoded_batches_through_the_mixer_and_the_service_equal_the_decoded_run
     # process_frames takes an encoded batch as well
     direct = svc.process_frames(batches[0][0], max_faces=3)
     assert len(direct) == 4
+
+
+def test_sizes_taken_from_a_stream_are_not_believed_beyond_a_frame(monkeypatch):
+    """round 4's advice: Content-Length (negative, huge), AVI chunk sizes and frames that never end are bounded"""
+    fr = _frames(3)
+    # multipart: a negative and an absurd Content-Length are ignored - the part is cut by its markers - and the stream goes on
+    body = b""
+    for i, f in enumerate(fr):
+        cl = [b"-5", b"99999999999", str(len(f)).encode()][i]
+        body += b"--b\r\nContent-Type: image/jpeg\r\nContent-Length: " + cl + b"\r\n\r\n" + f + b"\r\n"
+    assert [bytes(x) for x in mjpeg.multipart_frames(io.BytesIO(body))] == fr
+    # a frame that never ends is dropped once it has outgrown the limit; the frames behind it arrive
+    endless = fr[0][:-2] + b"\x11" * 5000                                  # no EOI, 5 kB of entropy-like bytes
+    stream = endless + fr[1] + fr[2]
+    got = list(mjpeg.split_stream([stream[i:i + 512] for i in range(0, len(stream), 512)], max_frame_bytes=len(fr[0]) + 1000))
+    assert [bytes(x) for x in got][-2:] == [fr[1], fr[2]] and len(got) <= 3
+    got = list(mjpeg.multipart_frames(io.BytesIO(b"--b\r\n\r\n" + stream), max_frame_bytes=len(fr[0]) + 1000))
+    assert [bytes(x) for x in got][-2:] == [fr[1], fr[2]]
+    # AVI: a video chunk larger than the limit is skipped by its length, not read
+    avi = mjpeg.write_avi(fr, (96, 128), fps=5)
+    if avi is not None:
+        assert [bytes(x) for x in mjpeg.avi_frames(io.BytesIO(avi))] == fr
+        small = min(len(f) for f in fr)
+        kept = [bytes(x) for x in mjpeg.avi_frames(io.BytesIO(avi), max_frame_bytes=small)]
+        assert kept == [f for f in fr if len(f) <= small]
+
+
+def test_jpeg_end_resumes_where_it_stopped():
+    """the walk of a frame that arrives in pieces continues from its last position (state list) and finds the same end as a
+    walk of the whole frame - for every chunking, including cuts inside markers, segment lengths and stuffed bytes"""
+    f = _frames(1, hw=(160, 224), restart_marker_rows=1)[0] + b"\xff\xd8\xff"      # (a next frame's start behind it)
+    whole = mjpeg.jpeg_end(f, 0)
+    assert whole == len(f) - 3
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        cuts = sorted(set(int(c) for c in rng.integers(1, len(f), size=int(rng.integers(1, 30)))))
+        buf, state, end = bytearray(), [], None
+        for a, b in zip([0] + cuts, cuts + [len(f)]):
+            buf += f[a:b]
+            end = mjpeg.jpeg_end(buf, 0, state)
+            if end is not None:
+                break
+        assert end == whole, (trial, cuts)
+    # one byte at a time
+    buf, state = bytearray(), []
+    for i in range(len(f)):
+        buf.append(f[i])
+        if mjpeg.jpeg_end(buf, 0, state) is not None:
+            break
+    assert mjpeg.jpeg_end(buf, 0, state) == whole
