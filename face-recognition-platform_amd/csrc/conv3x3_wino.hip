@@ -34,6 +34,7 @@
 // backend/app/services/face_service.py:179).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "frp_internal.h"
 #include "conv_common.h"
 
@@ -89,20 +90,32 @@ __device__ __forceinline__ void wino_tile_epilogue(const ConvParams& p, floatx16
                                                    int fr, int fh, int HoWo, float inv_howo, float inv_wo, int m_over = 0) {
     // OVER / m_over (2-D tiles): pixel index of the lane's pair (its even pixel), -1 for a pair that does not exist
     const bool has_res = RES < 0 ? p.res != nullptr : RES != 0;
-    uint4 rr[2][PB][1][2];
+#ifndef WN_RES_UPFRONT
+#define WN_RES_UPFRONT 1
+#endif
+    // Round 5: the residual of ALL four units is requested before the first one is finished (32 registers: the k-loop's fragment
+    // registers are dead here) - one L2 round trip per tile exposed instead of one per unit (the request for unit u + 1 went out
+    // when unit u started, and a unit's arithmetic is shorter than the latency).  WN_RES_UPFRONT=0: the former order (A/B).
+    constexpr int NRR = (WN_RES_UPFRONT && PB == 1) ? 4 : 2;
+    uint4 rr[NRR][PB][1][2];
     auto load_res = [&](int c, int par, uint4 (&r)[PB][1][2]) { wino_load_res<PB, OVER>(p, r, c, par, m0, c0, pair0, crow0, fr, fh, m_over); };
-    if (has_res) load_res(0, 0, rr[0]);
+    if (has_res) {
+        if constexpr (NRR == 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_res(u >> 1, u & 1, rr[u]);
+        } else load_res(0, 0, rr[0]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int c = u >> 1, par = u & 1;
-        if (has_res && u < 3) load_res((u + 1) >> 1, (u + 1) & 1, rr[(u + 1) & 1]);
+        if constexpr (NRR == 2) { if (has_res && u < 3) load_res((u + 1) >> 1, (u + 1) & 1, rr[(u + 1) & 1]); }
         floatx16 y[PB][1];
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 y[b][0][e] = par ? (acc[1][b][c][e] - acc[2][b][c][e]) - acc[3][b][c][e] : (acc[0][b][c][e] + acc[1][b][c][e]) + acc[2][b][c][e];
-        conv_epilogue_body<PB, 1, WN_TC_, FULL, ACT, RES, OVER>(p, y, rr[u & 1], lds_bias, lds_slope, m0, c0, pair0, crow0 + c * 32, fr, fh, HoWo,
+        conv_epilogue_body<PB, 1, WN_TC_, FULL, ACT, RES, OVER>(p, y, rr[NRR == 4 ? u : (u & 1)], lds_bias, lds_slope, m0, c0, pair0, crow0 + c * 32, fr, fh, HoWo,
                                                                 inv_howo, inv_wo, 2, par, m_over);
     }
 }
@@ -1006,11 +1019,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2_kernel(ConvParams p_in) 
 // A tile carries 240 real pixels in 256 pixel slots and the edge tiles of a map carry less; against that stand the kernel's x1.12
 // (128 channels: 24 sub-steps per tile, a third of a tile is prologue + epilogue) and x1.2 (256 channels and more) over the direct
 // kernel.  Measured (tools/wino_probe.py, 32 frames): 136 x 240 x 128: x1.08-1.11, 68 x 120 x 256: x1.09, 68 x 120 x 128: x1.00,
-// 34 x 60 x 256: x0.98; with a residual at 128 channels x1.08 alone but nothing in the pipeline.  Fewer than two rounds of tiles: the
-// direct family (its quarter tiles fill the chip better).
+// 34 x 60 x 256: x0.98.  Fewer than two rounds of tiles: the direct family (its quarter tiles fill the chip better).
 bool conv3x3_wino_wide_pays(int N, int H, int W, int Cin, int Cout, int n_cu, bool has_res) {
     if ((W & 1) || W <= 30 || Cin < 128 || (Cin & 63)) return false;
-    if (has_res && Cin < 256) return false;     // (in the pipeline the 136 x 240 x 128 residual layers ran 302 / 318 us against 310 / 305 direct)
+    // (round 4 kept the 136 x 240 x 128 RESIDUAL layers direct: 302 / 318 us against 310 / 305 in the pipeline.  With the residual of
+    // all four epilogue units requested up front - round 5 - they take the 2-D tiles too: detector 5.065 -> 5.038 ms per 32 frames,
+    // gpurun_out -> profiles/r5/ab_residual_epilogue.txt.)
+    (void)has_res;
     const long ty = (H + 7) / 8, tx = (W + 29) / 30;
     const long tiles = (long)N * ty * tx * ((Cout + WN_TC - 1) / WN_TC);
     if (tiles < 2L * (n_cu > 0 ? n_cu : 256)) return false;
