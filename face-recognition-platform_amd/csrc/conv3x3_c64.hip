@@ -1,0 +1,315 @@
+// K2d: 3x3 stride-1 convolution 64 -> 64 channels - the layers that live on the LARGEST maps (the detector's 272 x 480 stage,
+// the embedder's 112 x 112 and 56 x 56 stage: 8 launches, 1.5 ms of an 11.5 ms step in round 4, at 650-920 TFLOP/s).
+//
+// Why its own kernel.  With 64 input channels a tile's whole contraction is 9 k-steps: in the row-patch kernel
+// (conv3x3_lean.hip, 512 x 64 tiles) every tile pays a ring hand-over, nine barriers, nine weight stages of LDS-DMA and an
+// epilogue for 8.7 us of k-loop, and the 64-cout tile re-reads every weight fragment from LDS.  Here
+//   * the WEIGHTS never move after the prologue: a wave owns 32 couts, and the 36 A fragments of their whole K = 576 sit in 144
+//     registers for the life of the workgroup - no weight DMA, no weight fragment reads, no weight ring;
+//   * the pixel operand is a 2-D tile (8 rows x 32 columns of one image; halo'd patch 10 x 34 pixels) brought in by LDS-DMA into a
+//     three-slot ring, TWO tiles ahead; out-of-image pixels are zero-filled by the DMA itself (per-lane source offsets pushed out of
+//     the buffer's range), so fragment reads need no masks and no zero block;
+//   * a tile is ONE barrier: all 72 MFMAs of a wave (2 pixel blocks x 36 k-slices) run on fragments of one patch, one
+//     ds_read_b128 per MFMA, every one of them at the block's base register + an immediate (144-byte pixel pitch: C64_PITCH);
+//   * stores are unconditional buffer stores (pixels that do not exist get an out-of-range offset), so the in-order memory
+//     counter is exact and the wait in front of a tile's barrier admits the next tile's DMA and the last epilogue's stores.
+// Eight waves = 4 pixel groups (tile rows 2g, 2g + 1) x 2 cout groups; accumulation order (kh, kw, 16-channel slice) and
+// epilogue arithmetic are those of the other direct kernels: bit-identical results (tests: test_conv_c64_equals_generic_kernel).
+//
+// Replaces the same reference calls as conv_mfma.hip (face_recognition.face_locations / face_encodings,
+// backend/app/routes/camera.py:232,237).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "frp_internal.h"
+#include "conv_common.h"
+
+namespace frp {
+
+#define C64_TH 8
+#define C64_TW 32
+#define C64_PW (C64_TW + 2)                 // patch columns
+#define C64_ROWS ((C64_TH + 2) * C64_PW)    // 340 patch pixels
+#define C64_PITCH 144                       // LDS bytes per patch pixel: 128 + one 16-byte pad slot.  9 sixteen-byte slots per pixel
+                                            // make consecutive pixels walk all 16 slot positions of the 256-byte bank row (9 is odd), so
+                                            // a ds_read_b128's 16-lane groups are conflict-free WITHOUT an xor swizzle - and without
+                                            // one every (tap, 16-channel slice) of a pixel block is the block's base address + an
+                                            // immediate: no vector instruction in the k-loop (with the xor layout of the other kernels a
+                                            // tile cost 72 v_xor + 90 address operations per wave, and the loop was VALU-issue-bound)
+#define C64_PIECES 48                       // LDS-DMA pieces per patch (1 KiB = 7.1 pixels each; 340 x 144 B = 47.8 KiB: six per wave)
+#define C64_BUF (C64_PIECES * 1024)
+#define C64_NBUF 3
+#define C64_OFF_PAR (C64_NBUF * C64_BUF)
+#define C64_LDS (C64_OFF_PAR + 10 * 64 * 4)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Specialised at compile time on (activation, residual, border-class bias): with the flags as run-time values the epilogue was a
+// chain of ~90 uniform branches and the register allocator spilled eleven registers, each reload a vmcnt(0) in the tile loop.
+template <int ACT, bool RES, bool BORDER>
+__global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    ConvParams p = p_in;
+    int N = p.N;
+    if (p.n_dev) {                             // image count known on the device only (threshold mode)
+        const int n = *p.n_dev;
+        N = n < 0 ? 0 : (n > p.N ? p.N : n);
+    }
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tx_n = (p.W + C64_TW - 1) / C64_TW, ty_n = (p.H + C64_TH - 1) / C64_TH;
+    const int per = tx_n * ty_n;
+    const int n_tiles = N * per;
+    int t0, t1, tstep;
+    if ((gridDim.x & 7) == 0) {                // XCD-interleaved tile walk (see conv3x3_lean.hip)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, pr = gridDim.x >> 3;
+        const int cs = (int)((long)x * n_tiles / 8), ce = (int)((long)(x + 1) * n_tiles / 8);
+        t0 = cs + j;
+        t1 = ce;
+        tstep = pr;
+    } else {
+        t0 = (int)((long)blockIdx.x * n_tiles / gridDim.x);
+        t1 = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+        tstep = 1;
+    }
+    if (t0 >= t1) return;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const unsigned o_bytes = (unsigned)((long)p.N * p.H * p.W * 64 * 2);             // (< 2 GiB: launcher)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.x), 0, p.res ? o_bytes : 0u, 0x00020000);
+
+    // ---------------- epilogue parameters, once per workgroup (one cout tile): bias [9][64] (class-major), PReLU slope [64]
+    float* lds_bias = reinterpret_cast<float*>(smem + C64_OFF_PAR);
+    float* lds_slope = lds_bias + 9 * 64;
+    constexpr bool border = BORDER;
+    for (int i = t; i < 9 * 64; i += 512) lds_bias[i] = (border || i < 64) ? p.bias[i] : 0.f;
+    if (t < 64) lds_slope[t] = (ACT == FRP_ACT_PRELU && p.slope) ? p.slope[t] : 0.f;
+
+    // ---------------- this wave's weights: 32 couts x K = 576 as 36 MFMA A fragments (k-slice s = tap * 4 + kk: channels 16 kk + 8 fh .. + 7)
+    const int wave_p = wave >> 1, wave_c = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    half8 A[36];
+    {
+        const _Float16* wrow = p.w + (long)(wave_c * 32 + fr) * 576 + 8 * fh;
+#pragma unroll
+        for (int s = 0; s < 36; ++s) A[s] = *reinterpret_cast<const half8*>(wrow + (s >> 2) * 64 + (s & 3) * 16);
+    }
+
+    // ---------------- DMA lane geometry: piece j of this wave fills the 16-byte slots 64 (wave + 8 j) + lane of a patch buffer; slot q
+    // = chunk q % 9 (8: the pad) of patch pixel R = q / 9 = (R / 34, R % 34)
+    // (recomputed per piece from the lane index - a dozen vector operations against twelve registers held through the k-loop,
+    // whose 144 weight registers leave no room for tables; lane_e is made opaque per tile so that the compiler does not build the
+    // tables after all)
+    int lane_e = lane;
+    struct Patch { int base, y0, x0; bool live; };          // scalars of a tile's patch (image coordinates of its origin)
+    auto patch_of = [&](int tile) -> Patch {
+        Patch q{0, 0, 0, tile < t1};
+        if (q.live) {
+            const int n = tile / per, r = tile - n * per;
+            const int ty = r / tx_n, tx = r - ty * tx_n;
+            q.y0 = ty * C64_TH - 1;
+            q.x0 = tx * C64_TW - 1;
+            q.base = ((n * p.H + q.y0) * p.W + q.x0) * 128;
+        }
+        return q;
+    };
+    auto issue_piece = [&](const Patch& q, int j, int slot) {
+        const int sl = (wave + 8 * j) * 64 + lane_e;
+        const int R = (sl * 7282) >> 16, chunk = sl - 9 * R;               // sl / 9, sl % 9 (exact for sl < 3072)
+        const int py = (R * 241) >> 13, px = R - py * C64_PW;              // R / 34, R % 34 (exact for R < 384)
+        const int y = q.y0 + py, x = q.x0 + px;
+        const bool ok = q.live && R < C64_ROWS && chunk < 8 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        dma16(xrsrc, smem + slot * C64_BUF + (wave + 8 * j) * 1024, ok ? (unsigned)(q.base + (py * p.W + px) * 128 + chunk * 16) : CONV_OOB);
+    };
+    auto issue_patch = [&](int tile, int slot) {
+        const Patch q = patch_of(tile);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) issue_piece(q, j, slot);
+    };
+
+    // ---------------- fragment addresses: pixel block b = tile row 2 wave_p + b, lane = column fr; tap (kh, kw), slice kk reads patch
+    // pixel (row + kh, fr + kw), chunk 2 kk + fh: the block's base + the immediate ((kh * 34 + kw) * 144 + kk * 32)
+    const int fbase = ((2 * wave_p) * C64_PW + fr) * C64_PITCH + fh * 16;
+
+    __syncthreads();                           // parameters visible (no LDS-DMA in flight yet: the fence costs nothing)
+    issue_patch(t0, 0);
+    issue_patch(t0 + tstep, 1);
+    constexpr bool has_res = RES;
+
+    int slot = 0;
+    for (int ct = t0; ct < t1; ct += tstep) {
+        // tile ct has landed: behind its pieces in the in-order counter sit the next tile's six pieces and - from the second tile
+        // on - the four stores of the last epilogue (unconditional: the count is exact)
+        if (ct == t0) wait_vmcnt<6>();
+        else if (has_res) wait_vmcnt<14>();    // (the epilogue's four residual loads sit in front of its stores)
+        else wait_vmcnt<10>();
+        retire_lds_reads();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" : "+v"(lane_e));
+        int nslot = slot + 2;
+        nslot = nslot >= C64_NBUF ? nslot - C64_NBUF : nslot;
+        // the patch two tiles ahead goes out BETWEEN the MFMAs below (its address arithmetic hides under matrix time; it has two
+        // tiles to land); past the end: zero-fill into a slot nobody reads
+        const Patch nq = patch_of(ct + 2 * tstep);
+
+        const int n = ct / per, r = ct - n * per;
+        const int ty = r / tx_n, tx = r - ty * tx_n;
+        const int oy0 = ty * C64_TH + 2 * wave_p, ox = tx * C64_TW + fr;
+        const int boff = slot * C64_BUF;
+
+        floatx16 acc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        half8 bf[3][2];                        // fragments of k-slices s, s + 1, s + 2 (requested two slices ahead of their MFMAs)
+        const unsigned char* pb = smem + (fbase + boff);
+        auto rd = [&](int s, int S) {
+            const int tap = s >> 2, kk = s & 3;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                bf[S][b] = *reinterpret_cast<const half8*>(pb + ((b + tap / 3) * C64_PW + tap % 3) * C64_PITCH + kk * 32);
+        };
+        rd(0, 0);
+        rd(1, 1);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 2 < 36) rd(s + 2, (s + 2) % 3);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bf[s % 3][b], acc[b], 0, 0, 0);
+            if (s % 5 == 4 && s / 5 < 6) issue_piece(nq, s / 5, nslot);
+            __builtin_amdgcn_sched_barrier(0);             // (the slices stay in this order: the compiler pulls the reads next to their MFMAs)
+        }
+
+        // ---------------- epilogue: lane = pixel (oy0 + b, ox), registers 4g .. 4g+3 = couts 32 wave_c + 8g + 4 fh .. + 3
+        u32x4 rr[2][2];
+        unsigned ooff[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oy = oy0 + b;
+            const bool ok = oy < p.H && ox < p.W;
+            const int m = (n * p.H + oy) * p.W + ox;
+            ooff[b] = ok ? (unsigned)(m * 128 + wave_c * 64 + fh * 16) : CONV_OOB;
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) rr[b][q] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ooff[b] + 32 * q, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oy = oy0 + b;
+            int cls = 0;
+            if (border) cls = ((oy == 0) ? 0 : (oy == p.H - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.W - 1) ? 2 : 1);
+            half4 r4[4];
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x4 v = rr[b][q];
+                    unsigned x_ = v.x, y_ = v.y, z_ = v.z, w_ = v.w;
+                    swap_halves(x_, z_);
+                    swap_halves(y_, w_);
+                    union { unsigned u[2]; half4 h; } lo, hi;
+                    lo.u[0] = x_; lo.u[1] = y_; hi.u[0] = z_; hi.u[1] = w_;
+                    r4[2 * q] = lo.h;
+                    r4[2 * q + 1] = hi.h;
+                }
+            }
+            union { half4 h; unsigned u[2]; } pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wave_c * 32 + 8 * g + 4 * fh;
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(lds_bias + cls * 64 + cl);
+                floatx4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[b][4 * g + e] + b4[e];
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[g][e];
+                }
+                if (ACT == FRP_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (ACT == FRP_ACT_PRELU) {
+                    const floatx4 s4 = *reinterpret_cast<const floatx4*>(lds_slope + cl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * s4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[g].h[e] = (_Float16)v[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                const u32x4 o = {pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[b] + 32 * q, 0, 0);   // couts 32 wave_c + 16 q + 8 fh .. + 7
+            }
+        }
+        slot = slot + 1 == C64_NBUF ? 0 : slot + 1;
+    }
+    // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
+    wait_vmcnt<0>();
+}
+
+static int c64_variant(const ConvParams& p);
+// Shapes the kernel covers (`p` with launch_conv()'s derived fields) - and where it pays: at least two rounds of tiles.
+bool conv3x3_c64_eligible(const ConvParams& p) {
+    if (p.KS != 3 || p.stride != 1 || p.Cin != 64 || p.Cout != 64 || p.ksplit != 1 || p.x2 || p.out2) return false;
+    if (p.flags & (FRP_FLAG_OUT_F32 | FRP_FLAG_F8 | FRP_FLAG_OUT_FP8 | FRP_FLAG_RES_UP2)) return false;
+    if (p.Ho != p.H || p.Wo != p.W) return false;
+    if ((long)p.N * p.H * p.W * 128 >= 0x7f000000L) return false;                  // signed 32-bit byte offsets (+ a patch of slack)
+    if (!c64_variant(p)) return false;
+    if (p.act == FRP_ACT_PRELU && !p.slope) return false;
+    const long ty = (p.H + C64_TH - 1) / C64_TH, tx = (p.W + C64_TW - 1) / C64_TW;
+    const long tiles = (long)p.N * ty * tx;
+    if (tiles < 2L * (p.n_cu > 0 ? p.n_cu : 256)) return false;
+    // where it pays (tools/c64_probe.py, profiles/r5/c64_probe.txt): x1.11 / x1.14 over the row-patch kernel on the detector's 272 x 480
+    // maps, whose 32-column tiles are all full; x0.99-1.03 on the embedder's 112 x 112 and 56 x 56 maps, where every fourth / second
+    // tile column is half empty - those stay on the row-patch kernel (FRP_C64_ALL=1 takes every eligible shape: the parity tests)
+    static const bool all = getenv("FRP_C64_ALL") != nullptr;
+    return all || (double)p.H * p.W >= 0.95 * (double)(ty * C64_TH) * (double)(tx * C64_TW);
+}
+
+template <int ACT, bool RES, bool BORDER>
+static hipError_t launch_c64_cfg(const ConvParams& p, hipStream_t stream) {
+    static bool attr_set[64] = {};
+    auto kern = conv3x3_c64_kernel<ACT, RES, BORDER>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const int ncu = device_cu_count(dev);
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    const long tiles = (long)p.N * ((p.H + C64_TH - 1) / C64_TH) * ((p.W + C64_TW - 1) / C64_TW);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(tiles < ncu ? tiles : ncu);       // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, stream, p);
+    return hipGetLastError();
+}
+
+// the four (activation, residual, border bias) combinations the two networks have on these layers
+static int c64_variant(const ConvParams& p) {
+    const bool res = p.res != nullptr, border = (p.flags & FRP_FLAG_BORDER_BIAS) != 0;
+    if (p.act == FRP_ACT_RELU && !border) return res ? 2 : 1;          // detector layer1
+    if (p.act == FRP_ACT_PRELU && !res && border) return 3;            // IResNet conv1 (folded pre-conv BN: 9 bias classes)
+    if (p.act == FRP_ACT_NONE && res && !border) return 4;             // IResNet conv2
+    return 0;
+}
+
+hipError_t launch_conv3x3_c64(const ConvParams& p, hipStream_t stream) {
+    if (!conv3x3_c64_eligible(p)) return hipErrorInvalidValue;
+    switch (c64_variant(p)) {
+        case 1: return launch_c64_cfg<FRP_ACT_RELU, false, false>(p, stream);
+        case 2: return launch_c64_cfg<FRP_ACT_RELU, true, false>(p, stream);
+        case 3: return launch_c64_cfg<FRP_ACT_PRELU, false, true>(p, stream);
+        case 4: return launch_c64_cfg<FRP_ACT_NONE, true, false>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace frp

@@ -34,6 +34,7 @@
 //   * 3x3 stride-1 layers with Cin % 64 == 0 go to conv3x3_rows.hip (row patches) instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "frp_internal.h"
 #include "conv_common.h"
@@ -535,6 +536,12 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     if (p.wino_w && !p.x2 && !(p.dbg & 1) && conv3x3_wino_eligible(p)) {      // Winograd F(2,3) along the rows: 1.5 x fewer MFMAs
         p.w = p.wino_w;
         return launch_conv3x3_wino(p, stream);
+    }
+    // 64 -> 64 layers on large maps: weights in registers, 2-D tiles (conv3x3_c64.hip; dbg bit 512 / FRP_NO_C64=1: the row-patch
+    // kernel instead - A/B runs; bit-identical results either way)
+    {
+        static const bool no_c64 = getenv("FRP_NO_C64") != nullptr;
+        if (!no_c64 && !(p.dbg & (1 | 512)) && p.small_m <= 0 && conv3x3_c64_eligible(p)) return launch_conv3x3_c64(p, stream);
     }
 #ifdef FRP_LAB   // lab build: dbg bits select the first-generation kernel and its timing ablations (conv3x3_rows.hip)
     if (!(p.dbg & 1) && !p.x2 && conv3x3_rows_eligible(p)) return launch_conv3x3_rows(p, stream);

@@ -67,6 +67,9 @@ bool conv3x3_rows_eligible(const ConvParams& p);
 hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);   // first generation + ablations (lab build only)
 #endif
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // static k-loop generation (conv3x3_lean.hip)
+// 3x3 stride-1 64 -> 64 layers on large maps (conv3x3_c64.hip): weights resident in registers, 2-D pixel tiles, one barrier per tile
+bool conv3x3_c64_eligible(const ConvParams& p);
+hipError_t launch_conv3x3_c64(const ConvParams& p, hipStream_t stream);
 // Winograd F(2,3) along the image rows (conv3x3_wino.hip): eligibility of a shape (`p` with launch_conv()'s derived fields),
 // the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
 bool conv3x3_wino_eligible(const ConvParams& p);

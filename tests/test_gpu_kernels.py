@@ -1,4 +1,6 @@
 """GPU parity tests of the individual HIP kernels, through the C ABI, against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -112,6 +114,50 @@ def test_conv_row_patch_kernel_equals_generic_kernel(engine, case):
     a = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT)
     b = engine.conv2d(x, w, bias, stride=1, act=act, slope=slope, res=res, flags=flags | TILES_DEFAULT | (1 << 8))
     assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+# 64 -> 64 layers on large maps (conv3x3_c64.hip: weights in registers, 8 x 32-pixel tiles, one barrier per tile; taken from two
+# rounds of tiles - 512 - on): the four (activation, residual, border-bias) combinations of the two networks, maps whose last
+# tile column / row is ragged (56 = 32 + 24 columns; 100 = 12.5 tile rows), images that end inside a workgroup's walk
+C64_CASES = [
+    # N, H, W, act, res, flags
+    (4, 136, 240, 1, False, 0),      # detector layer1 conv1 shape class: ReLU
+    (6, 100, 210, 1, True, 0),       # ... conv2: residual + ReLU, ragged rows and columns
+    (40, 56, 56, 2, False, 1),       # IResNet conv1: PReLU + 9 border-bias classes
+    (11, 112, 112, 0, True, 0),      # IResNet conv2: residual, no activation
+    (600, 7, 33, 1, False, 0),       # many small images: one tile row, two tile columns (the second 1 pixel wide)
+]
+NO_C64 = 0x100000
+
+
+@pytest.mark.parametrize("case", C64_CASES)
+def test_conv_c64_vs_fp32_reference_and_generic_kernel(engine, case, monkeypatch):
+    """the dedicated 64 -> 64 kernel against the fp32 reference (the direct kernels' bar) and - same k order, same epilogue
+    arithmetic - BIT FOR BIT against the row-patch kernel (flags bit 20 keeps it off) and the generic kernel (dbg 1); 12 more
+    launches return the bits of the first (its LDS ring runs two tiles ahead of the MFMAs)."""
+    N, H, W, act, has_res, flags = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, 64)).astype(np.float16)
+    w = (rng.standard_normal((64, 3, 3, 64)) / 24).astype(np.float16)
+    bias = rng.standard_normal((9, 64) if flags & 1 else (64,)).astype(np.float32) * 0.3
+    slope = rng.uniform(0.1, 0.4, 64).astype(np.float32) if act == 2 else None
+    res = rng.standard_normal((N, H, W, 64)).astype(np.float16) if has_res else None
+    kw = dict(stride=1, act=act, slope=slope, res=res)
+    # (the launcher routes only maps whose tiles are at least 95 % full to this kernel; FRP_C64_ALL - read once per process - takes
+    # every eligible shape: set in tests/conftest.py for the GPU session, so the ragged cases below do run it)
+    assert os.environ.get("FRP_C64_ALL") == "1"
+    out = engine.conv2d(x, w, bias, flags=flags | TILES_DEFAULT, **kw)
+    lean = engine.conv2d(x, w, bias, flags=flags | TILES_DEFAULT | NO_C64, **kw)
+    generic = engine.conv2d(x, w, bias, flags=flags | TILES_DEFAULT | (1 << 8), **kw)
+    assert np.array_equal(lean.view(np.uint16), generic.view(np.uint16))
+    bad = np.argwhere(out.view(np.uint16) != generic.view(np.uint16))
+    assert len(bad) == 0, f"{len(bad)} elements differ from the generic kernel; first {bad[:4].tolist()}"
+    sub = slice(0, min(N, 3))                                   # (the fp32 reference on the first images: CPU time)
+    ref = _conv_ref(x[sub], w, bias, 1, act, slope, None if res is None else res[sub], flags)
+    assert np.abs(out[sub].astype(np.float32) - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    for _ in range(12):
+        again = engine.conv2d(x, w, bias, flags=flags | TILES_DEFAULT, **kw)
+        assert np.array_equal(out.view(np.uint16), again.view(np.uint16))
 
 
 # cases the quarter-tile configurations cover with the k order of the default tiles (fp16 output, no split-K)
