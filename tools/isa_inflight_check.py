@@ -7,8 +7,9 @@ destination registers are not valid yet, so a register copy / spill / reuse it p
 would read (or be overwritten by) a value that arrives later - a timing-dependent wrong result.  This walks the kernel
 linearly (LDS operations return in order; `lgkmcnt(N)` leaves the N youngest outstanding; scalar memory reads count in the
 same counter, out of order: any of them outstanding makes only lgkmcnt(0) reliable, as the hardware documents) and reports
-every instruction that reads or writes a vector register with an outstanding LDS read into it.  Branch targets reset nothing:
-the walk is conservative for straight-line loop bodies, which is what these kernels are.
+every instruction that reads or writes a vector register with an outstanding LDS read into it.  Conditional branch targets
+reset nothing: the walk is conservative for straight-line loop bodies, which is what these kernels are; behind an unconditional
+branch or s_endpgm the walk starts afresh (out-of-line blocks).
 
     hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only -o k.s file.hip
     tools/isa_inflight_check.py k.s <mangled kernel name>
@@ -44,6 +45,9 @@ def check(lines):
         if not s or s.startswith('.') or s.endswith(':'):
             continue
         op = s.split()[0]
+        if op in ('s_endpgm', 's_branch', 's_setpc_b64'):
+            pending = []        # the next line is only reached by a jump (out-of-line blocks behind the kernel's body): not this path
+            continue
         if op == 's_waitcnt':
             m = re.search(r'lgkmcnt\((\d+)\)', s)
             if m:
