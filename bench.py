@@ -373,7 +373,18 @@ def main():
     if use_dist:
         import torch
         from frp_amd import dist as fdist
-        fdist.allgather_gallery_into_engine(lanes, N, lambda first, cnt: gallery_rows(N, first, cnt), local_rank)
+        # the collective runs on the LIBRARY's own RCCL communicator (frp_dist_* / frp_gallery_allgather: no torch tensor on the data
+        # plane; torch.distributed carries the 128-byte id and the timing reductions).  FRP_DIST_TORCH=1, or a failed native
+        # initialisation, takes the torch.distributed collective into the same reserved snapshot - the line says which one ran.
+        gather_path = "native RCCL (frp_gallery_allgather)"
+        try:
+            if os.environ.get("FRP_DIST_TORCH") == "1":
+                raise RuntimeError("FRP_DIST_TORCH=1")
+            fdist.native_allgather_gallery(lanes, N, lambda first, cnt: gallery_rows(N, first, cnt), dist.get_rank(), dist.get_world_size(),
+                                           fdist.share_id_over_torch)
+        except Exception as ex_:       # (every rank takes the same branch: the id exchange and the init are collectives that fail together)
+            gather_path = f"torch.distributed all_gather_into_tensor ({type(ex_).__name__}: {ex_})"
+            fdist.allgather_gallery_into_engine(lanes, N, lambda first, cnt: gallery_rows(N, first, cnt), local_rank)
         # every rank must now hold the same matrix: checksum of the committed snapshot (device memory), compared across ranks
         g_view = torch.as_tensor(fdist._DevicePtr(eng.gallery_device_ptr(), N, 512), device=torch.device("cuda", local_rank))
         gallery_sum = fdist.gallery_checksum(g_view)
@@ -795,6 +806,7 @@ def main():
                 "fp8_launches_per_step": ctr["f8_conv_launches"] // max(1, args.steps)}
         if dist is not None:       # (single-process runs keep the line byte-compatible: no extra keys)
             out["config"]["rccl_ranks"] = rccl_ranks
+            out["config"]["gallery_allgather"] = gather_path
             out["config"]["faces_per_s_per_rank"] = per_rank
             out["config"]["gathered_gallery_checksum"] = gallery_sum
             out["config"]["launcher"] = ("bench.py started its own ranks (torch.distributed.run, 127.0.0.1)"

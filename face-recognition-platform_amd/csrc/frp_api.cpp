@@ -2,6 +2,8 @@
 // detect -> align -> embed -> match pipeline on one HIP stream, per-stage HIP-event timing.
 // Interface and the reference call sites each entry point replaces: include/frp.h.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library opens librccl at first use (frp_dist_*)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -82,6 +84,9 @@ struct frp_handle {
     bool det_scaled = false;
     int canvas_h = 0, canvas_w = 0;
     int det_op_limit = -1;           // >= 0: frp_debug_det_prefix - the detector program stops behind this many ops
+    // multi-GPU (frp_dist_init): this handle's RCCL communicator, rank and world size
+    void* comm = nullptr;
+    int dist_rank = 0, dist_world = 0;
     DevBuf det_hashes;               // frp_debug_det_hashes: one 64-bit hash per detector op, taken right behind the op
     bool det_hash_on = false;
     // per-call results (device)
@@ -123,6 +128,36 @@ int fail(frp_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
     return code;
 }
+
+// librccl, opened at first use (frp_dist_*: the gallery all-gather; a process that never goes multi-GPU does not load it)
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) r.err = "librccl lacks an expected symbol";
+    });
+    return r;
+}
+
 
 #define HIPCHK(h, expr)                                                                              \
     do {                                                                                             \
@@ -1062,6 +1097,7 @@ void frp_destroy(frp_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->comm) { (void)rccl().CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
@@ -1323,6 +1359,104 @@ int frp_gallery_commit(frp_handle* h, int64_t n_rows) {
     release(h->gx);
     h->gx = fresh_x;
     h->g_rows = n_rows;
+    return FRP_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU: the one collective of the path, on RCCL
+// frames are sharded one stream per GPU and need no exchange; the watch list is the exception - every rank decrypts /
+// builds N / R rows and the full unit fp16 matrix is all-gathered over xGMI at load and on updates (the reference holds ENCODINGS
+// once, in its one process: backend/app/state.py:78).  The library owns that collective: librccl is opened at first use (dlopen - a
+// process that never goes multi-GPU does not load it), the communicator lives in the handle, and the gather lands STRAIGHT in a
+// reserved snapshot (shard r at row offset r * ceil(N / R): no compaction copy) that is then committed like any other gallery.
+// The caller's launcher (torch.distributed.run, MPI, a shell loop) only has to carry the 128-byte unique id from rank 0 to the others.
+static_assert(sizeof(ncclUniqueId) == FRP_DIST_ID_BYTES, "include/frp.h: FRP_DIST_ID_BYTES");
+
+int frp_dist_unique_id(void* id128) {
+    if (!id128) return FRP_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.err.empty()) return FRP_ERR_HIP;
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) return FRP_ERR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return FRP_OK;
+}
+
+int frp_dist_init(frp_handle* h, const void* id128, int32_t rank, int32_t world) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!id128 || world <= 0 || rank < 0 || rank >= world) return fail(h, FRP_ERR_INVALID, "bad rank / world size");
+    if (h->comm) return fail(h, FRP_ERR_INVALID, "this handle already has a communicator (frp_dist_destroy first)");
+    Rccl& r = rccl();
+    if (!r.err.empty()) return fail(h, FRP_ERR_HIP, r.err);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const ncclResult_t e = r.CommInitRank(&c, world, id, rank);          // collective over the ranks (the guard has set this handle's device)
+    if (e != ncclSuccess) return fail(h, FRP_ERR_HIP, std::string("ncclCommInitRank: ") + r.GetErrorString(e));
+    h->comm = c;
+    h->dist_rank = rank;
+    h->dist_world = world;
+    return FRP_OK;
+}
+
+int frp_dist_destroy(frp_handle* h) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (h->comm) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)rccl().CommDestroy((ncclComm_t)h->comm);
+        h->comm = nullptr;
+        h->dist_world = 0;
+    }
+    return FRP_OK;
+}
+
+int frp_gallery_allgather(frp_handle* h, const void* shard, int64_t shard_rows, int32_t dtype, int64_t n_total) {
+    if (!h) return FRP_ERR_INVALID;
+    Guard g(h);
+    if (!h->comm) return fail(h, FRP_ERR_INVALID, "no communicator (frp_dist_init)");
+    if (h->g_reserved.p) return fail(h, FRP_ERR_INVALID, "a gallery reservation is pending: commit or cancel it first");
+    const int world = h->dist_world, rank = h->dist_rank;
+    if (n_total <= 0 || n_total > 0x7fffff00L || shard_rows < 0 || (shard_rows > 0 && !shard)) return fail(h, FRP_ERR_INVALID, "bad shard");
+    const int64_t block = (n_total + world - 1) / world;
+    const int64_t first = std::min<int64_t>((int64_t)rank * block, n_total), mine = std::min<int64_t>(block, n_total - first);
+    if (shard_rows != mine) return fail(h, FRP_ERR_INVALID, "this rank owns rows [rank * ceil(N / R), ...): shard has another row count");
+    Rccl& r = rccl();
+    // this rank's rows, unit fp16, padded with zero rows to the block size (the last ranks' shards may be short or empty)
+    DevBuf send;
+    FRPCHK(ensure(h, send, (size_t)block * FRP_EMB_DIM * 2));
+    int rc = FRP_OK;
+    hipError_t he = hipMemsetAsync(send.p, 0, (size_t)block * FRP_EMB_DIM * 2, h->stream);
+    if (he != hipSuccess) rc = fail(h, FRP_ERR_HIP, std::string("memset: ") + hipGetErrorString(he));
+    if (rc == FRP_OK && mine > 0) {
+        std::vector<float> f;
+        const float* rows = (const float*)shard;
+        if (dtype != FRP_F32) { rc = to_f32(h, shard, (size_t)mine * FRP_EMB_DIM, dtype, f); rows = f.data(); }
+        if (rc == FRP_OK) rc = upload_rows_normalized(h, rows, mine, (_Float16*)send.p);
+    }
+    if (rc == FRP_OK) rc = ensure(h, h->g_reserved, (size_t)world * block * FRP_EMB_DIM * 2);
+    if (rc == FRP_OK) {
+        const ncclResult_t e = r.AllGather(send.p, h->g_reserved.p, (size_t)block * FRP_EMB_DIM, ncclFloat16, (ncclComm_t)h->comm, h->stream);
+        if (e != ncclSuccess) rc = fail(h, FRP_ERR_HIP, std::string("ncclAllGather: ") + r.GetErrorString(e));
+    }
+    if (rc == FRP_OK) {
+        he = hipStreamSynchronize(h->stream);
+        if (he != hipSuccess) rc = fail(h, FRP_ERR_HIP, std::string("all-gather: ") + hipGetErrorString(he));
+    }
+    release(send);
+    if (rc != FRP_OK) { release(h->g_reserved); return rc; }
+    // commit (as frp_gallery_commit): rows [0, n_total) of the gathered blocks ARE the gallery
+    DevBuf fresh_x;
+    if (h->g_exact) {
+        rc = exact_from_f16(h, h->g_reserved.p, n_total, fresh_x);
+        if (rc != FRP_OK) { release(h->g_reserved); return rc; }
+    }
+    release(h->gallery);
+    h->gallery = h->g_reserved;
+    h->g_reserved = DevBuf();
+    release(h->gx);
+    h->gx = fresh_x;
+    h->g_rows = n_total;
     return FRP_OK;
 }
 

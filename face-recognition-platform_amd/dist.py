@@ -110,6 +110,39 @@ def allgather_gallery_into_engine(engine, n_total: int, make_rows: Callable[[int
     return n_total
 
 
+def native_allgather_gallery(engine, n_total: int, make_rows: Callable[[int, int], np.ndarray], rank: int, world: int,
+                             share_id: Callable[[bytes | None], bytes], gallery=None) -> int:
+    """The same collective on the LIBRARY's own RCCL communicator (include/frp.h: frp_dist_unique_id / frp_dist_init /
+    frp_gallery_allgather): no torch tensor, no torch collective on the data plane - the launcher only carries 128 bytes.
+    `share_id(id_or_None) -> id`: the control channel; rank 0 calls it with a fresh id, the others with None, all get the id back
+    (`share_id_over_torch` below, an MPI bcast, a file on shared storage ...).  Rank r builds rows shard_range(n_total, r, world) on
+    the host; the first engine gathers straight into a reserved snapshot and commits it; further lanes of this GPU copy theirs
+    from it.  The communicator stays with the engine (later watch-list reloads gather again without a new id)."""
+    if gallery is not None:
+        with gallery.locked():
+            return native_allgather_gallery(engine, n_total, make_rows, rank, world, share_id)
+    from . import native
+    engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+    e0 = engines[0]
+    if getattr(e0, "_dist", None) is None:
+        uid = share_id(native.Engine.dist_unique_id() if rank == 0 else None)
+        e0.dist_init(uid, rank, world)
+    first, cnt = shard_range(n_total, rank, world)
+    rows = np.ascontiguousarray(make_rows(first, cnt), dtype=np.float32) if cnt else np.zeros((0, 512), np.float32)
+    e0.gallery_allgather(rows, n_total)
+    for e in engines[1:]:                                    # every lane of this GPU matches against its own copy
+        e.gallery_set_device(e0.gallery_device_ptr(), n_total)
+    return n_total
+
+
+def share_id_over_torch(payload, src: int = 0) -> bytes:
+    """control channel for `native_allgather_gallery` when torch.distributed is the launcher: an object broadcast (host side)"""
+    import torch.distributed as dist
+    box = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def broadcast_names(names: Sequence[str], src: int = 0) -> List[str]:
     """The host-side name table travels as a Python object broadcast (not on the data path)."""
     import torch.distributed as dist

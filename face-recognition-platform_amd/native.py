@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_cancel", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
     "frp_jpeg_info_get", "frp_jpeg_coefficients", "frp_upload_jpeg_async",
+    "frp_dist_unique_id", "frp_dist_init", "frp_dist_destroy", "frp_gallery_allgather",
     "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
     "frp_host_alloc", "frp_host_free", "frp_upload_frames_async", "frp_swap_frames",
@@ -182,6 +183,10 @@ def load_library() -> C.CDLL:
     lib.frp_get_det_source.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.frp_finish_faces.argtypes = [vp, i32, vp, vp, vp, vp, i32, u32, vp, vp, vp]
     lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.frp_dist_unique_id.argtypes = [vp]
+    lib.frp_dist_init.argtypes = [vp, vp, i32, i32]
+    lib.frp_dist_destroy.argtypes = [vp]
+    lib.frp_gallery_allgather.argtypes = [vp, vp, i64, i32, i64]
     lib.frp_debug_det_prefix.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.frp_debug_det_hashes.argtypes = [vp, i32, vp]
     lib.frp_decode_heads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp, vp, vp, vp, vp]
@@ -267,6 +272,36 @@ class Engine:
 
     def gallery_set_device(self, dev_ptr: int, n: int):
         self._chk(self._lib.frp_gallery_set_device(self._h, C.c_void_p(dev_ptr), n, EMB_DIM))
+
+    # -- multi-GPU: the gallery all-gather on the library's own RCCL communicator (include/frp.h: frp_dist_*)
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        """rank 0: a fresh 128-byte communicator id (carry it to the other ranks by any control channel)"""
+        buf = C.create_string_buffer(128)
+        rc = load_library().frp_dist_unique_id(buf)
+        if rc != 0:
+            raise FrpError(rc, "frp_dist_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def dist_init(self, unique_id: bytes, rank: int, world: int):
+        """collective: this handle's communicator"""
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id has 128 bytes")
+        self._chk(self._lib.frp_dist_init(self._h, C.c_char_p(unique_id), rank, world))
+        self._dist = (rank, world)
+
+    def dist_destroy(self):
+        self._chk(self._lib.frp_dist_destroy(self._h))
+        self._dist = None
+
+    def gallery_allgather(self, shard: np.ndarray, n_total: int):
+        """collective: this rank's rows (host [rows, 512], any float dtype) -> the full unit fp16 gallery on every rank"""
+        shard = np.ascontiguousarray(shard)
+        if shard.dtype not in (np.float32, np.float16, np.float64):
+            shard = shard.astype(np.float32)
+        code = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.float64): 2}[shard.dtype]
+        shard = shard.reshape(-1, 512)
+        self._chk(self._lib.frp_gallery_allgather(self._h, _ptr(shard) if shard.shape[0] else None, shard.shape[0], code, n_total))
 
     def gallery_reserve(self, capacity_rows: int) -> int:
         """device address of a fresh, not yet visible snapshot of capacity_rows x 512 fp16 (fill it, then gallery_commit)"""

@@ -206,6 +206,24 @@ int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_
  * device half runs asynchronously on the copy stream. */
 int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B);
 
+/* ---- multi-GPU: one process per GPU, ONE collective ----------------------------------------------------
+ * Frames are sharded one stream per GPU and never exchanged.  The watch list is: every rank builds (decrypts) rows
+ * [rank * ceil(N / R), ...) and the unit fp16 matrix is all-gathered over RCCL / xGMI straight into a reserved snapshot of
+ * every rank's handle, then committed - replaces the single in-process dict of the reference (backend/app/state.py:78,
+ * rebuilt per call at face_service.py:409).  The library owns the collective (librccl opened at first use); the launcher
+ * only carries the 128-byte unique id from rank 0 to the other ranks (any control channel: a file, MPI, torch.distributed
+ * object broadcast - frp_amd/dist.py). */
+#define FRP_DIST_ID_BYTES 128
+/* rank 0: a fresh communicator id */
+int frp_dist_unique_id(void* id128);
+/* collective over `world` ranks (each on its own GPU): creates this handle's communicator */
+int frp_dist_init(frp_handle* h, const void* id128, int32_t rank, int32_t world);
+int frp_dist_destroy(frp_handle* h);
+/* collective: `shard` = this rank's rows [shard_rows, 512] in HOST memory (dtype FRP_F32 / FRP_F16 / FRP_F64 as
+ * frp_gallery_set; normalised on upload), shard_rows = min(block, n_total - rank * block) with block = ceil(n_total / world).
+ * On return every rank's gallery is the full [n_total, 512] matrix, rows in rank order. */
+int frp_gallery_allgather(frp_handle* h, const void* shard, int64_t shard_rows, int32_t dtype, int64_t n_total);
+
 /* ---- stage entry points (REST paths and parity tests) ------------------------------- */
 /* detection only -> face_recognition.face_locations (camera.py:232) */
 int frp_detect(frp_handle* h, const uint8_t* bgr, int32_t B, int32_t H, int32_t W, int64_t row_stride,

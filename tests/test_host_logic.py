@@ -802,3 +802,55 @@ def test_process_stream_two_lanes_host_logic():
     solo._eng().process_frames = canned_for(solo._eng(), "solo")
     assert solo.store_face("id0", E[0].tolist())["success"]
     assert len(list(solo.process_stream(batches[:3], max_faces=1))) == 3
+
+
+def test_native_allgather_helper_hands_every_rank_its_own_rows(monkeypatch):
+    """dist.native_allgather_gallery (the library-owned RCCL collective: include/frp.h frp_dist_* / frp_gallery_allgather), host side,
+    against recording engines: rank 0 mints the id and every rank gets it through the control channel, each rank builds exactly
+    rows shard_range(N, r, R) - contiguous ceil(N / R) blocks, the last ranks short or empty -, the first lane gathers and the
+    other lanes of the GPU copy its snapshot.  (The collective itself: tests/test_gpu_service.py, one rank; bench.py --gpus N.)"""
+    from frp_amd import dist as fdist, native
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+            self._dist = None
+
+        def dist_init(self, uid, rank, world):
+            self.calls.append(("init", uid, rank, world))
+            self._dist = (rank, world)
+
+        def gallery_allgather(self, rows, n_total):
+            self.calls.append(("gather", rows.copy(), n_total))
+
+        def gallery_device_ptr(self):
+            return 0xABC0
+
+        def gallery_set_device(self, ptr, n):
+            self.calls.append(("copy", ptr, n))
+
+    monkeypatch.setattr(native.Engine, "dist_unique_id", staticmethod(lambda: b"\x07" * 128))
+    N, R = 1001, 4
+    table = np.arange(N * 512, dtype=np.float32).reshape(N, 512)
+    shared = {}
+
+    def channel(payload):
+        if payload is not None:
+            shared["id"] = payload
+        return shared["id"]
+    seen = []
+    for rank in range(R):
+        lanes = [Rec(), Rec()]
+        n = fdist.native_allgather_gallery(lanes, N, lambda first, cnt: table[first:first + cnt], rank, R, channel)
+        assert n == N
+        kind, uid, r_, w_ = lanes[0].calls[0]
+        assert (kind, uid, r_, w_) == ("init", b"\x07" * 128, rank, R)
+        kind, rows, n_total = lanes[0].calls[1]
+        first, cnt = fdist.shard_range(N, rank, R)
+        assert kind == "gather" and n_total == N and rows.shape == (cnt, 512) and np.array_equal(rows, table[first:first + cnt])
+        assert lanes[1].calls == [("copy", 0xABC0, N)]
+        seen.append((first, cnt))
+        # a second gather on the same engines reuses the communicator
+        fdist.native_allgather_gallery(lanes, N, lambda first, cnt: table[first:first + cnt], rank, R, channel)
+        assert [c[0] for c in lanes[0].calls] == ["init", "gather", "gather"]
+    assert seen == [(0, 251), (251, 251), (502, 251), (753, 248)]
