@@ -252,6 +252,7 @@ def run_config4(args, json_fd):
                                          ("ms_preprocess", "ms_det_conv", "ms_decode", "ms_align", "ms_emb_conv", "ms_l2norm", "ms_match")}},
         "roofline": {"bound": "mfma", "kernel": "conv family (detector at 3 scales + embedder)", "achieved": round(achieved, 2),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel_source_sha256_16": native.kernel_source_hash(),
                      "match_kernel": {"bound": "hbm", "achieved": round(match_gbs, 1) if match_gbs else None, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(match_gbs / HBM_PEAK_GBS, 4) if match_gbs else None,
                                       "bytes_per_launch": N * 512 * 2}},

@@ -5,7 +5,7 @@
 # microarchitecture guide prescribes) summarised per kernel family, SQ counters of the stage-3 conv shape.
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/${1:-r4final}
+O=$R/gpurun_out/${1:-r5final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 \
@@ -35,6 +35,10 @@ echo "SQ pass (Winograd kernel) done"
 (cd $R && FRP_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 10 --warmup 2 --cpu-frames 0 > $O/bench_dist_rehearsal_1rank.json 2> $O/bench_dist_rehearsal.err) || true
 echo "RCCL rehearsal done"
+# the other two GPU configurations of BASELINE.json on the same sources (their lines carry the source hash)
+(cd $R && python3 bench.py --workload config4 > $O/bench_config4.json 2> $O/bench_config4.err) || true
+(cd $R && python3 bench.py --workload config5 > $O/bench_config5.json 2> $O/bench_config5.err) || true
+echo "config 4 / config 5 lines done"
 cd $R
 python tools/layer_times.py $(find $O/kt_timed -name "*kernel_trace.csv" | head -1) > $O/layer_times.txt
 python tools/pmc_summarise.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) 3 \
