@@ -112,6 +112,8 @@ struct frp_handle {
     size_t jpeg_pin_cap[2] = {0, 0};
     int jpeg_turn = 0;
     DevBuf jpeg_coef, jpeg_planes;
+    int64_t ctr_jpeg_device_batches = 0;   // batches whose entropy decode ran on the device (frp_debug_jpeg_device_batches)
+    DevBuf jpeg_scan, jpeg_err;      // device entropy decode (restart-interval streams): compressed scans + interval offsets + tables; per-image error flags
     hipEvent_t ev_jpeg_h2d[2] = {nullptr, nullptr};     // the copy out of jpeg_pin[i] has finished
     bool jpeg_h2d_pending[2] = {false, false};
     // exact compat rows (frp_gallery_exact): float64 [g_rows x 512] as enrolled, next to the unit fp16 snapshot
@@ -1102,7 +1104,7 @@ void frp_destroy(frp_handle* h) {
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
                      &h->q16, &h->part_cos, &h->part_idx, &h->best_cos, &h->best_idx, &h->scratch, &h->splitk_ws, &h->dense_logits, &h->scaled, &h->gallery,
-                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes, &h->det_hashes};
+                     &h->g_reserved, &h->gx, &h->gx_q, &h->gx_out, &h->jpeg_coef, &h->jpeg_planes, &h->jpeg_scan, &h->jpeg_err, &h->det_hashes};
     for (DevBuf* b : all) release(*b);
     for (int i = 0; i < EV_COUNT; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i) {
@@ -1653,6 +1655,111 @@ int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_
     return jpeg_decode_coefficients(data, size, coef, coef_elems, qtab, info, nullptr);
 }
 
+// Device entropy decode of a batch whose frames all carry restart intervals (round 5; jpeg_kernels.hip: jpeg_huffman_kernel): the host
+// parses headers and finds the RSTn markers (one memchr pass), the COMPRESSED scans go to the device (~0.5 MB per 1080p frame instead of
+// 6.3 MB of coefficients), one thread per interval decodes, and the host waits only for the per-image error flags (a corrupt stream
+// must be reported by this call, as on the host path) before the pixel kernels are queued.  -> FRP_OK, an error, or 1 = "not this
+// batch" (not switched on, no restart intervals, too few of them to fill a wave): the caller takes the host decoder.
+namespace {
+int upload_jpeg_device(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B, const frp_jpeg_info& I, int turn,
+                       JpegParams& p, size_t total_host_layout, size_t q_off) {
+    // When: one thread per interval decodes 32 x 1080p frames in 17.8 ms at one interval per MCU row (120 MCUs), 4.5 ms at 30 MCUs,
+    // 1.25 ms at 8 (profiles/r5/jpeg_device_entropy.txt) - the time goes with the LENGTH of an interval, and 16 host threads take
+    // 9-12 ms: by default the device decodes streams whose intervals are at most 32 MCUs and the host the others.
+    // FRP_JPEG_DEVICE_HUFFMAN=1 (read once): the device whatever the interval (takes the entropy decode off the host's cores; at
+    // one interval per row it is slower than the pipeline consumes frames), =0: never.
+    static const int mode = [] { const char* e = getenv("FRP_JPEG_DEVICE_HUFFMAN"); return !e ? 0 : (e[0] == '0' ? -1 : 1); }();
+    if (mode < 0 || I.restart_interval <= 0 || (mode == 0 && I.restart_interval > 32)) return 1;
+    const long mcus = (long)I.mcus_x * I.mcus_y;
+    const long n_int = (mcus + I.restart_interval - 1) / I.restart_interval;
+    if ((long)B * n_int < 64 || n_int > 0x7fffff) return 1;
+    std::vector<JpegDevicePlan> plans((size_t)B);
+    std::vector<JpegHuffTableDev> tabs((size_t)B * 6);
+    for (int i = 0; i < B; ++i) {
+        std::string e;
+        if (!jpegs[i]) return fail(h, FRP_ERR_INVALID, "JPEG " + std::to_string(i) + ": null image");
+        const int rc = jpeg_plan_device_decode(jpegs[i], sizes[i], plans[i], tabs.data() + (size_t)i * 6, &e);
+        if (rc != FRP_OK) {
+            if (plans[i].info.restart_interval <= 0 && plans[i].info.width > 0) return 1;          // a frame without intervals: host path for the batch
+            return fail(h, rc, "JPEG " + std::to_string(i) + ": " + e);
+        }
+        const frp_jpeg_info& Ii = plans[i].info;
+        if (Ii.width != I.width || Ii.height != I.height || Ii.components != I.components || Ii.h_samp[0] != I.h_samp[0] || Ii.v_samp[0] != I.v_samp[0])
+            return fail(h, FRP_ERR_INVALID, "JPEG " + std::to_string(i) + ": geometry differs from image 0 (one batch = one frame size and sampling)");
+        if (Ii.restart_interval != I.restart_interval) return 1;
+    }
+    // staging layout: scans | interval offsets | tables | quantisation tables | error flags (read back)
+    std::vector<size_t> soff((size_t)B + 1, 0);
+    for (int i = 0; i < B; ++i) soff[i + 1] = (soff[i] + plans[i].scan_bytes + 15) & ~(size_t)15;
+    if (soff[B] >= 0xfffffff0u) return 1;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_int = up(soff[B]), o_tab = up(o_int + (size_t)B * (n_int + 1) * 4), o_q = up(o_tab + (size_t)B * 6 * sizeof(JpegHuffTableDev)),
+                 o_err = up(o_q + (size_t)B * 192 * 2), stage_total = o_err + (size_t)B * 4;
+    if (h->jpeg_h2d_pending[turn]) {
+        HIPCHK(h, hipEventSynchronize(h->ev_jpeg_h2d[turn]));
+        h->jpeg_h2d_pending[turn] = false;
+    }
+    if (stage_total > h->jpeg_pin_cap[turn]) {
+        if (h->jpeg_pin[turn]) { (void)hipHostFree(h->jpeg_pin[turn]); h->jpeg_pin[turn] = nullptr; h->jpeg_pin_cap[turn] = 0; }
+        if (hipHostMalloc(&h->jpeg_pin[turn], stage_total, hipHostMallocDefault) != hipSuccess) return fail(h, FRP_ERR_OOM, "hipHostMalloc (JPEG staging) failed");
+        h->jpeg_pin_cap[turn] = stage_total;
+    }
+    if (!h->ev_jpeg_h2d[turn]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_jpeg_h2d[turn], hipEventDisableTiming));
+    char* st = (char*)h->jpeg_pin[turn];
+    uint32_t* io = (uint32_t*)(st + o_int);
+    for (int i = 0; i < B; ++i) {
+        memcpy(st + soff[i], plans[i].scan, plans[i].scan_bytes);
+        for (long k = 0; k <= n_int; ++k) io[(size_t)i * (n_int + 1) + k] = (uint32_t)(soff[i] + plans[i].int_off[(size_t)k]);
+        memcpy(st + o_q + (size_t)i * 384, plans[i].qtab, 384);
+    }
+    memcpy(st + o_tab, tabs.data(), tabs.size() * sizeof(JpegHuffTableDev));
+    const size_t need = (size_t)B * I.height * I.width * 3;
+    if (need > h->frames_next.cap || !h->frames_next.p || total_host_layout > h->jpeg_coef.cap || (size_t)B * p.plane_img > h->jpeg_planes.cap ||
+        o_err > h->jpeg_scan.cap || (size_t)B * 4 > h->jpeg_err.cap) {
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // growing buffers: nothing may still be copying into / computing from them
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        FRPCHK(ensure(h, h->frames_next, need));
+        FRPCHK(ensure(h, h->jpeg_coef, total_host_layout));
+        FRPCHK(ensure(h, h->jpeg_planes, (size_t)B * p.plane_img));
+        FRPCHK(ensure(h, h->jpeg_scan, o_err));
+        FRPCHK(ensure(h, h->jpeg_err, (size_t)B * 4));
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_next_free, 0));
+    HIPCHK(h, hipMemcpyAsync(h->jpeg_scan.p, st, o_err, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipMemsetAsync(h->jpeg_coef.p, 0, q_off, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync((char*)h->jpeg_coef.p + q_off, (char*)h->jpeg_scan.p + o_q, (size_t)B * 384, hipMemcpyDeviceToDevice, h->copy_stream));
+    HIPCHK(h, hipMemsetAsync(h->jpeg_err.p, 0, (size_t)B * 4, h->copy_stream));
+    JpegHuffParams hp{};
+    hp.scan = (const uint8_t*)h->jpeg_scan.p;
+    hp.int_off = (const uint32_t*)((const char*)h->jpeg_scan.p + o_int);
+    hp.tables = (const JpegHuffTableDev*)((const char*)h->jpeg_scan.p + o_tab);
+    hp.coef = (int16_t*)h->jpeg_coef.p;
+    hp.err = (int32_t*)h->jpeg_err.p;
+    hp.coef_per_image = (long)jpeg_coef_elems(I);
+    hp.B = B; hp.n_int = (int)n_int; hp.ri = I.restart_interval;
+    hp.mcus_x = I.mcus_x; hp.mcus_y = I.mcus_y; hp.components = I.components;
+    for (int c = 0; c < 3; ++c) { hp.hs[c] = I.h_samp[c]; hp.vs[c] = I.v_samp[c]; hp.bx[c] = p.bx[c]; hp.comp_off[c] = p.plane_off[c]; }
+    hipError_t e = launch_jpeg_huffman(hp, h->copy_stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("jpeg huffman: ") + hipGetErrorString(e));
+    HIPCHK(h, hipMemcpyAsync(st + o_err, h->jpeg_err.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));          // the flags decide this call's return value (and the staging buffer is free again)
+    const int32_t* flags = (const int32_t*)(st + o_err);
+    for (int i = 0; i < B; ++i)
+        if (flags[i]) return fail(h, FRP_ERR_INVALID, "JPEG " + std::to_string(i) + ": corrupt or truncated entropy-coded data");
+    p.coef = (const int16_t*)h->jpeg_coef.p;
+    p.qtab = (const uint16_t*)((const char*)h->jpeg_coef.p + q_off);
+    p.planes = (uint8_t*)h->jpeg_planes.p;
+    p.frames = (uint8_t*)h->frames_next.p;
+    e = launch_jpeg_decode(p, h->copy_stream);
+    if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("jpeg decode: ") + hipGetErrorString(e));
+    HIPCHK(h, hipEventRecord(h->ev_next_ready, h->copy_stream));
+    h->nB = B; h->nH = I.height; h->nW = I.width;
+    h->next_valid = true;
+    h->ctr_jpeg_device_batches += 1;
+    return FRP_OK;
+}
+}  // namespace
+
 int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h, false);      // copy stream only (as frp_upload_frames_async)
@@ -1665,6 +1772,24 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
     const size_t coef_bytes = (size_t)B * ce * 2, q_off = (coef_bytes + 255) & ~(size_t)255, total = q_off + (size_t)B * 3 * 64 * 2;
     const int turn = h->jpeg_turn;
     h->jpeg_turn ^= 1;
+    JpegParams p{};
+    p.B = B; p.W = I.width; p.H = I.height; p.components = I.components;
+    p.hs = I.h_samp[0]; p.vs = I.v_samp[0];
+    p.cw = (I.width + p.hs - 1) / p.hs;
+    p.ch = (I.height + p.vs - 1) / p.vs;
+    long off = 0;
+    for (int c = 0; c < I.components; ++c) {
+        p.bx[c] = I.mcus_x * I.h_samp[c];
+        p.by[c] = I.mcus_y * I.v_samp[c];
+        p.blocks_per_image += p.bx[c] * p.by[c];
+        p.plane_off[c] = off;
+        off += (long)p.bx[c] * p.by[c] * 64;
+    }
+    p.plane_img = off;
+    {   // restart-interval streams: entropy decode on the device
+        const int dr = upload_jpeg_device(h, jpegs, sizes, B, I, turn, p, total, q_off);
+        if (dr != 1) return dr;
+    }
     if (h->jpeg_h2d_pending[turn]) {                 // the copy of the batch before the previous one read this staging buffer
         HIPCHK(h, hipEventSynchronize(h->ev_jpeg_h2d[turn]));
         h->jpeg_h2d_pending[turn] = false;
@@ -1702,20 +1827,6 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
     }
     for (int i = 0; i < B; ++i)
         if (rcs[i] != FRP_OK) return fail(h, rcs[i], "JPEG " + std::to_string(i) + ": " + errs[i]);
-    JpegParams p{};
-    p.B = B; p.W = I.width; p.H = I.height; p.components = I.components;
-    p.hs = I.h_samp[0]; p.vs = I.v_samp[0];
-    p.cw = (I.width + p.hs - 1) / p.hs;
-    p.ch = (I.height + p.vs - 1) / p.vs;
-    long off = 0;
-    for (int c = 0; c < I.components; ++c) {
-        p.bx[c] = I.mcus_x * I.h_samp[c];
-        p.by[c] = I.mcus_y * I.v_samp[c];
-        p.blocks_per_image += p.bx[c] * p.by[c];
-        p.plane_off[c] = off;
-        off += (long)p.bx[c] * p.by[c] * 64;
-    }
-    p.plane_img = off;
     const size_t need = (size_t)B * I.height * I.width * 3;
     if (need > h->frames_next.cap || !h->frames_next.p || total > h->jpeg_coef.cap || (size_t)B * off > h->jpeg_planes.cap) {
         HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // growing buffers: nothing may still be copying into / computing from them
@@ -1738,6 +1849,13 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
     h->nB = B; h->nH = I.height; h->nW = I.width;
     h->next_valid = true;
     return FRP_OK;
+}
+
+// diagnostic: how many frp_upload_jpeg_async batches had their entropy decode on the device (restart-interval streams)
+int64_t frp_debug_jpeg_device_batches(frp_handle* h) {
+    if (!h) return -1;
+    Guard g(h, false);
+    return h->ctr_jpeg_device_batches;
 }
 
 int frp_swap_frames(frp_handle* h) {

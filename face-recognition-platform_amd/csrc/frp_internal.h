@@ -17,6 +17,8 @@
 #define FRP_MAX_FACES_CAP 128
 #endif
 
+#include "jpeg_host.h"
+
 namespace frp {
 
 struct ConvParams {
@@ -157,6 +159,23 @@ struct JpegParams {
     int cw, ch;              // real extent of the chroma planes: ceil(W / hs), ceil(H / vs)
 };
 hipError_t launch_jpeg_decode(const JpegParams& p, hipStream_t stream);
+
+// Entropy decoding ON THE DEVICE for streams with restart intervals (round 5): the DC predictors reset at every RSTn marker, so the
+// intervals of a scan are independent bit streams - one thread each (jpeg_kernels.hip: jpeg_huffman_kernel).  Canonical Huffman
+// tables: jpeg_host.h: JpegHuffTableDev.
+struct JpegHuffParams {
+    const uint8_t* scan;             // the entropy-coded segments of all images, back to back
+    const uint32_t* int_off;         // [B][n_int + 1]: byte offset (into `scan`) of every interval's first byte; [n_int] = one past the image's data
+    const JpegHuffTableDev* tables;  // [B][6]: component c's DC table at 2c, its AC table at 2c + 1
+    int16_t* coef;                   // out: [B][coef_per_image], natural order (zeroed before the launch)
+    int32_t* err;                    // out: [B], non-zero = the image's bit stream is corrupt / ends early
+    long coef_per_image;
+    int B, n_int, ri;                // intervals per image, MCUs per interval
+    int mcus_x, mcus_y, components;
+    int hs[3], vs[3], bx[3];         // sampling factors and blocks per row of each component
+    long comp_off[3];                // first coefficient of each component inside an image
+};
+hipError_t launch_jpeg_huffman(const JpegHuffParams& p, hipStream_t stream);
 
 // u8 bilinear resize for the detection pyramid (frames [B,H,W,3] tightly packed)
 hipError_t launch_tensor_hash(const void* src, size_t bytes, unsigned long long* slot, hipStream_t stream);

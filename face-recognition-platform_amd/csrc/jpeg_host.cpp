@@ -417,4 +417,69 @@ int jpeg_decode_coefficients(const uint8_t* data, size_t size, int16_t* coef, si
     return FRP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Plan of a device-side entropy decode (restart-interval streams).  The host's part shrinks to the headers and ONE pass over
+// the scan for 0xFF bytes: every RSTn marker starts an independent interval (T.81 F.1.1.5: the DC predictors and the bit
+// alignment reset there).
+static void flatten_table(const HuffTable& t, JpegHuffTableDev& d) {
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < 512; ++i) {
+        const uint16_t f = t.fast[i << (kFast - 9)];
+        d.fast[i] = (f && (f >> 8) <= 9) ? f : 0;
+    }
+    for (int l = 0; l < 17; ++l) { d.mincode[l] = t.mincode[l]; d.valptr[l] = t.valptr[l]; }
+    for (int l = 0; l < 18; ++l) d.maxcode[l] = t.maxcode[l];
+    d.mincode[0] = d.valptr[0] = 0;
+    d.maxcode[0] = -1;
+    memcpy(d.vals, t.vals, 256);
+}
+
+int jpeg_plan_device_decode(const uint8_t* data, size_t size, JpegDevicePlan& plan, JpegHuffTableDev* tables6, std::string* err) {
+    JpegHeaderInternal H;
+    const int rc = parse_headers(data, size, H);
+    plan.info = H.info;
+    if (rc != FRP_OK) { if (err) *err = H.err; return rc; }
+    const frp_jpeg_info& I = H.info;
+    if (I.restart_interval <= 0) { if (err) *err = "no restart intervals"; return FRP_ERR_INVALID; }
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 64; ++i) plan.qtab[c * 64 + i] = c < I.components ? H.qt[H.comp_tq[c]][i] : 1;
+    for (int c = 0; c < 3; ++c) {
+        const int cc = c < I.components ? c : 0;
+        flatten_table(H.dc[H.comp_td[cc]], tables6[2 * c]);
+        flatten_table(H.ac[H.comp_ta[cc]], tables6[2 * c + 1]);
+    }
+    const long mcus = (long)I.mcus_x * I.mcus_y;
+    const long n_int = (mcus + I.restart_interval - 1) / I.restart_interval;
+    if (n_int > 0x7fffff) { if (err) *err = "too many restart intervals"; return FRP_ERR_INVALID; }
+    plan.scan = H.scan;
+    plan.int_off.clear();
+    plan.int_off.reserve((size_t)n_int + 1);
+    plan.int_off.push_back(0);
+    const uint8_t* p = H.scan;
+    const uint8_t* const end = data + size;
+    int next_rst = 0;
+    const uint8_t* stop = end;                       // the first marker that is not RSTn (EOI normally), or the end of the file
+    while (p < end) {
+        p = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+        if (!p || p + 1 >= end) break;
+        const int m = p[1];
+        if (m == 0x00) { p += 2; continue; }         // stuffed byte
+        if (m == 0xFF) { ++p; continue; }            // fill byte
+        if (m >= 0xD0 && m <= 0xD7) {
+            if (m != 0xD0 + next_rst || (long)plan.int_off.size() >= n_int) { if (err) *err = "restart marker missing or out of sequence"; return FRP_ERR_INVALID; }
+            next_rst = (next_rst + 1) & 7;
+            plan.int_off.push_back((uint32_t)(p + 2 - H.scan));
+            p += 2;
+            continue;
+        }
+        stop = p;                                    // EOI / another segment: the scan ends here
+        break;
+    }
+    if ((long)plan.int_off.size() != n_int) { if (err) *err = "restart marker missing or out of sequence"; return FRP_ERR_INVALID; }
+    if ((size_t)(stop - H.scan) >= 0xfffffff0u) { if (err) *err = "scan too large"; return FRP_ERR_INVALID; }
+    plan.int_off.push_back((uint32_t)(stop - H.scan));
+    plan.scan_bytes = (size_t)(stop - H.scan);
+    return FRP_OK;
+}
+
 }  // namespace frp

@@ -193,6 +193,156 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(JpegParams p) {
     dst[2] = (uint8_t)r;
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Entropy decoding on the device (round 5): one THREAD per restart interval.  The DC predictors and the byte alignment reset at
+// every RSTn marker (T.81 F.1.1.5), so a scan with restart intervals is a set of independent bit streams: a 1080p 4:2:0 frame
+// with one interval per MCU row is 68 of them, a batch of 32 frames 2,176 threads.  Each walks its bytes (un-stuffing 0xFF00),
+// decodes with the image's own tables (copied to LDS: one workgroup = 64 intervals of ONE image) and scatters the non-zero
+// coefficients into the buffer the inverse-DCT kernel reads (zeroed before the launch).  The same canonical decoding as
+// jpeg_host.cpp - bit-identical coefficients (tests/test_gpu_pipeline.py: both paths against PIL).  What moves over PCIe is the
+// compressed stream (~0.5 MB per 1080p frame) instead of 6.3 MB of coefficients, and the host keeps its threads.
+struct DevBits {
+    const unsigned* wp;           // next aligned dword of the interval's bytes
+    unsigned long long raw;       // bytes fetched but not yet fed (next byte = bits 0..7)
+    int rawn;                     // ... how many
+    int left;                     // bytes of the interval not yet fed into the window (incl. those in `raw`)
+    unsigned long long acc;       // next bit of the stream = bit 63
+    int nbits;
+    int pad;                      // zero bits fed behind the end of the interval
+    // (bytes come in 8 at a time - two aligned dword loads -: fetched one by one, every lane of a wave waited a memory round trip
+    // per byte of its own stream and a batch of 32 x 1080p took 18 ms)
+    __device__ __forceinline__ void init(const uint8_t* p, const uint8_t* end) {
+        const unsigned long a = (unsigned long)p;
+        wp = reinterpret_cast<const unsigned*>(a & ~3ul);
+        const int skip_ = (int)(a & 3ul);
+        raw = (unsigned long long)(*wp++) >> (8 * skip_);
+        rawn = 4 - skip_;
+        left = (int)(end - p);
+        acc = 0;
+        nbits = 0;
+        pad = 0;
+    }
+    __device__ __forceinline__ unsigned next_byte() {          // only while left > 0
+        if (rawn == 0) {
+            const unsigned lo = wp[0], hi = wp[1];             // (reads up to 7 bytes past the interval: inside the staging buffer's padding)
+            wp += 2;
+            raw = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            rawn = 8;
+        }
+        const unsigned b = (unsigned)(raw & 0xffu);
+        raw >>= 8;
+        --rawn;
+        --left;
+        return b;
+    }
+    __device__ __forceinline__ void fill() {
+        while (nbits <= 56) {
+            unsigned b = 0;
+            if (left > 0) {
+                b = next_byte();
+                if (b == 0xFF) {                        // a stuffed zero follows; anything else is a marker INSIDE the interval: end of data
+                    unsigned n = 1;
+                    if (left > 0) n = next_byte();
+                    if (n != 0x00) { left = 0; b = 0; pad += 8; }
+                }
+            } else {
+                pad += 8;
+            }
+            acc |= (unsigned long long)b << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    __device__ __forceinline__ unsigned peek(int n) const { return (unsigned)(acc >> (64 - n)); }
+    __device__ __forceinline__ void skip(int n) { acc <<= n; nbits -= n; }
+    __device__ __forceinline__ int extend(int s) {
+        if (s == 0) return 0;
+        const int v = (int)peek(s);
+        skip(s);
+        return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    }
+    __device__ __forceinline__ int decode(const JpegHuffTableDev& t) {
+        const unsigned f = t.fast[peek(9)];
+        if (f) { skip((int)(f >> 8)); return (int)(f & 0xff); }
+        for (int len = 10; len <= 16; ++len) {
+            const int code = (int)peek(len);
+            if (t.maxcode[len] >= 0 && code <= t.maxcode[len] && code >= t.mincode[len]) {
+                skip(len);
+                return t.vals[t.valptr[len] + code - t.mincode[len]];
+            }
+        }
+        return -1;
+    }
+};
+
+__constant__ uint8_t kZigZagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffParams p) {
+    __shared__ JpegHuffTableDev tab[6];
+
+    __shared__ uint8_t zz[64];                 // (in LDS: indexed per lane - from constant memory every symbol waited a vector-memory round trip)
+    zz[threadIdx.x] = kZigZagDev[threadIdx.x];
+    const int b = blockIdx.y;
+    {   // this image's tables -> LDS (dwords: the struct is a multiple of 4 bytes)
+        const unsigned* src = reinterpret_cast<const unsigned*>(p.tables + (long)b * 6);
+        unsigned* dst = reinterpret_cast<unsigned*>(tab);
+        for (int i = threadIdx.x; i < (int)(6 * sizeof(JpegHuffTableDev) / 4); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= p.n_int) return;
+    const uint32_t* io = p.int_off + (long)b * (p.n_int + 1);
+    DevBits br;
+    // an interval ends where the next one's marker starts (2 bytes in front of the next interval's first byte); the last one at the end of the data
+    br.init(p.scan + io[it], p.scan + (it + 1 < p.n_int ? io[it + 1] - 2 : io[p.n_int]));
+    int16_t* coef = p.coef + (long)b * p.coef_per_image;
+    const long total = (long)p.mcus_x * p.mcus_y;
+    long m0 = (long)it * p.ri, m1 = m0 + p.ri;
+    m1 = m1 < total ? m1 : total;
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    bool bad = false;
+    for (long m = m0; m < m1 && !bad; ++m) {
+        const int my = (int)(m / p.mcus_x), mx = (int)(m - (long)my * p.mcus_x);
+        for (int c = 0; c < p.components && !bad; ++c) {
+            const JpegHuffTableDev& dct = tab[2 * c];
+            const JpegHuffTableDev& act = tab[2 * c + 1];
+            for (int v = 0; v < p.vs[c] && !bad; ++v)
+                for (int hh = 0; hh < p.hs[c] && !bad; ++hh) {
+                    int16_t* blk = coef + p.comp_off[c] + ((long)(my * p.vs[c] + v) * p.bx[c] + (mx * p.hs[c] + hh)) * 64;
+                    br.fill();
+                    const int s = br.decode(dct);
+                    if (s < 0 || s > 11) { bad = true; break; }
+                    const int diff = br.extend(s);
+                    int pr = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+                    pr += diff;
+                    if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+                    if (pr) blk[0] = (int16_t)pr;
+                    for (int k = 1; k < 64;) {
+                        br.fill();
+                        // (a combined code + magnitude look-up as in the host decoder, and refilling only below 32 bits, made this loop
+                        // SLOWER - 32 ms against 18 for 32 x 1080p: the lanes of a wave walk 64 different streams and every extra branch is
+                        // executed by all of them)
+                        const int rs = br.decode(act);
+                        if (rs < 0) { bad = true; break; }
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) { k += 16; continue; }
+                            break;                                   // end of block
+                        }
+                        k += r;
+                        if (k > 63) { bad = true; break; }
+                        blk[zz[k]] = (int16_t)br.extend(sz);
+                        ++k;
+                    }
+                }
+        }
+    }
+    // bits that were not in the interval were consumed: it ends before its last MCU (jpeg_host.cpp: ran_dry)
+    if (bad || br.nbits < br.pad) atomicOr(p.err + b, 1);
+}
+
 }  // namespace
 
 hipError_t launch_jpeg_decode(const JpegParams& p, hipStream_t stream) {
@@ -204,6 +354,14 @@ hipError_t launch_jpeg_decode(const JpegParams& p, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_jpeg_huffman(const JpegHuffParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.n_int <= 0 || p.ri <= 0 || p.components <= 0 || p.components > 3 || !p.scan || !p.int_off || !p.tables || !p.coef || !p.err)
+        return hipErrorInvalidValue;
+    if (p.B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)((p.n_int + 63) / 64), (unsigned)p.B), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -205,6 +205,9 @@ int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_
  * frp_upload_frames_async does for raw frames: follow with frp_swap_frames.  Returns when the coefficients are staged; the
  * device half runs asynchronously on the copy stream. */
 int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B);
+/* diagnostic: batches of this handle whose ENTROPY decode ran on the device too (every frame carries restart intervals of at most 32
+ * MCUs - one thread per interval; longer intervals: the host decoder, unless FRP_JPEG_DEVICE_HUFFMAN=1; =0: always the host) */
+int64_t frp_debug_jpeg_device_batches(frp_handle* h);
 
 /* ---- multi-GPU: one process per GPU, ONE collective ----------------------------------------------------
  * Frames are sharded one stream per GPU and never exchanged.  The watch list is: every rank builds (decrypts) rows

@@ -10,6 +10,8 @@ os.environ.setdefault("FACE_BACKUP_DIR", tempfile.mkdtemp(prefix="frp_backups_")
 # the 64 -> 64 conv kernel on every shape it covers (the launcher's default keeps ragged maps on the row-patch kernel, where both
 # run at the same speed: conv3x3_c64.hip); read once per process by the library, so it is set before the first launch
 os.environ.setdefault("FRP_C64_ALL", "1")
+# the device entropy decoder of restart-interval JPEG streams is opt-in (csrc/frp_api.cpp: upload_jpeg_device): on for the tests
+os.environ.setdefault("FRP_JPEG_DEVICE_HUFFMAN", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

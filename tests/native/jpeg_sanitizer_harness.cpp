@@ -36,6 +36,17 @@ int main(int argc, char** argv) {
                 free(coef);
             }
         }
+        {   // the plan of the device entropy decode (headers + restart-marker scan) over the same bytes
+            frp::JpegDevicePlan plan;
+            frp::JpegHuffTableDev tabs[6];
+            std::string e2;
+            const int rc2 = frp::jpeg_plan_device_decode(buf, (size_t)n, plan, tabs, &e2);
+            if (rc2 == FRP_OK) {
+                volatile unsigned sum = 0;
+                for (size_t k = 0; k + 1 < plan.int_off.size(); ++k) sum += plan.scan[plan.int_off[k] < plan.scan_bytes ? plan.int_off[k] : 0];
+                if (plan.scan_bytes) sum += plan.scan[plan.scan_bytes - 1];
+            }
+        }
         if (rc == FRP_OK) ++decoded; else ++refused;
         free(buf);
     }

@@ -1,4 +1,6 @@
 """GPU end-to-end parity of detect -> align -> embed -> match against the fp32 oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1150,6 +1152,106 @@ def test_jpeg_stills_decode_on_the_device(engine):
         engine.upload_jpeg_async([b.getvalue()])
     with pytest.raises(FrpError):
         engine.upload_jpeg_async([b"not a jpeg at all"])
+
+
+def test_jpeg_entropy_decode_on_the_device_for_restart_interval_streams(fresh_engine):
+    # (the path is opt-in - FRP_JPEG_DEVICE_HUFFMAN=1, read once per process: tests/conftest.py sets it for the GPU session; the
+    # host-decoder tests above use frames without restart intervals or too few of them, which never take it)
+    """frames that carry restart intervals (RSTn every MCU row - what most Motion-JPEG cameras emit -
+    or every few MCUs) have their ENTROPY decode on the device too: one thread per interval (jpeg_huffman_kernel), the compressed
+    scans over PCIe instead of coefficients.  Against PIL, bit for bit: every sampling, grayscale, frames without a DHT segment,
+    intervals of whole MCU rows / a few MCUs / one MCU, sizes that are no multiple of the MCU, 1080p; the path really ran
+    (`jpeg_device_batches`); a frame without intervals in the batch, or too few intervals to fill a wave, takes the host decoder
+    (same pixels); damaged streams - a truncated interval, a flipped byte, a marker out of sequence - are refused BY THIS CALL,
+    nothing staged."""
+    import io
+    from PIL import Image
+    from frp_amd import native
+    from frp_amd.native import FrpError
+    engine = fresh_engine
+    raw, blob = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    engine.load_weights(blob)
+    rng = np.random.default_rng(21)
+
+    def device_decode(jpegs):
+        engine.upload_jpeg_async(jpegs)
+        engine.swap_frames()
+        info = native.jpeg_info(jpegs[0])
+        engine.detect_resident((info["height"], info["width"]), max_faces=2, det_thresh=0.5)
+        return engine.det_source()
+
+    def pil_bgr(data):
+        return np.array(Image.open(io.BytesIO(data)).convert("RGB"))[..., ::-1]
+
+    def still(h, w, gray=False, **kw):
+        img = np.clip(rng.normal(120, 55, (h // 8 + 1, w // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:h, :w] + rng.normal(0, 7, (h, w, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        (Image.fromarray(img).convert("L") if gray else Image.fromarray(img)).save(b, "JPEG", **kw)
+        return b.getvalue()
+
+    def strip_dht(d):
+        out, i = bytearray(d[:2]), 2
+        while True:
+            m_, L = d[i + 1], (d[i + 2] << 8) | d[i + 3]
+            if m_ == 0xDA:
+                return bytes(out + d[i:])
+            if m_ != 0xC4:
+                out += d[i:i + 2 + L]
+            i += 2 + L
+
+    assert os.environ.get("FRP_JPEG_DEVICE_HUFFMAN") == "1"
+    n0 = engine.jpeg_device_batches()
+    ran = 0
+    cases = [(1080, 1920, 4, dict(quality=88, restart_marker_rows=1)), (720, 1280, 6, dict(quality=93, subsampling=0, restart_marker_rows=1)),
+             (481, 643, 5, dict(quality=70, subsampling=1, restart_marker_rows=2)), (243, 517, 8, dict(quality=80, subsampling=2, restart_marker_blocks=3)),
+             (97, 130, 3, dict(quality=90, subsampling=2, restart_marker_blocks=1)), (360, 640, 4, dict(quality=85, gray=True, restart_marker_rows=1)),
+             (360, 640, 4, dict(quality=85, subsampling=2, restart_marker_rows=1, bare=True))]
+    for (h, w, B, kw) in cases:
+        kw = dict(kw)
+        bare = kw.pop("bare", False)
+        imgs = [still(h, w, **kw) for _ in range(B)]
+        if bare:
+            imgs = [strip_dht(d) for d in imgs]
+        assert all(native.jpeg_info(d)["restart_interval"] > 0 for d in imgs)
+        got = device_decode(imgs)
+        for b in range(B):
+            ref = pil_bgr(imgs[b])
+            assert np.array_equal(got[b], ref), (h, w, kw, b, int(np.abs(got[b].astype(int) - ref).max()))
+        ran += 1
+        assert engine.jpeg_device_batches() == n0 + ran, (h, w, kw)
+    # not this path: one frame of the batch without intervals; a batch with fewer than 64 intervals in all
+    mixed = [still(360, 640, quality=85, restart_marker_rows=1), still(360, 640, quality=85)]
+    got = device_decode(mixed)
+    assert all(np.array_equal(got[b], pil_bgr(mixed[b])) for b in range(2)) and engine.jpeg_device_batches() == n0 + ran
+    few = [still(64, 64, quality=85, restart_marker_rows=1)]
+    assert np.array_equal(device_decode(few)[0], pil_bgr(few[0])) and engine.jpeg_device_batches() == n0 + ran
+    # damaged streams are refused by the call (the flags of the device decode are read before it returns)
+    good = [still(360, 640, quality=85, restart_marker_rows=1) for _ in range(4)]
+    d = good[2]
+    sos = d.find(b"\xff\xda")
+    rst = [i for i in range(sos, len(d) - 1) if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7]
+    assert len(rst) >= 10
+    cut = d[:rst[3] + 2 + (rst[4] - rst[3]) // 2] + d[rst[4]:]                  # half of interval 4 is missing
+    swapped = bytearray(d)
+    swapped[rst[5] + 1], swapped[rst[6] + 1] = d[rst[6] + 1], d[rst[5] + 1]      # RST5 and RST6 exchanged
+    for bad in (cut, bytes(swapped), d[:rst[8] + 2 + 5]):
+        with pytest.raises(FrpError):
+            engine.upload_jpeg_async(good[:2] + [bad] + good[3:])
+    # ... and a byte flipped inside an interval gives either an error or a decode - never a hang or a fault; the engine keeps working
+    for _ in range(20):
+        flip = bytearray(d)
+        i = int(rng.integers(rst[0] + 2, len(d) - 4))
+        if flip[i] == 0xFF or flip[i - 1] == 0xFF:
+            continue
+        flip[i] ^= int(rng.integers(1, 256))
+        if flip[i] == 0xFF:
+            continue
+        try:
+            engine.upload_jpeg_async(good[:3] + [bytes(flip)])
+        except FrpError:
+            pass
+    got = device_decode(good)
+    assert all(np.array_equal(got[b], pil_bgr(good[b])) for b in range(4))
 
 
 def test_staged_ingest_takes_the_device_decoder_for_jpeg_batches(engine):

@@ -17,13 +17,15 @@ from frp_amd import native  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 90
+RST = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # restart interval in MCU rows (0: none - the host entropy decoder; > 0: the
+                                                             # device's, unless FRP_JPEG_HOST_HUFFMAN=1 is set)
 frames = bench.synth_frames(B, 1080, 1920, 10, 77)
 jpegs = []
 for f in frames:
     b = io.BytesIO()
-    Image.fromarray(f[..., ::-1]).save(b, "JPEG", quality=Q)
+    Image.fromarray(f[..., ::-1]).save(b, "JPEG", quality=Q, **({"restart_marker_rows": RST} if RST else {}))
     jpegs.append(b.getvalue())
-print(f"{B} x 1080p JPEG stills, quality {Q}: {sum(map(len, jpegs)) / B / 1e3:.0f} kB each; host threads available: {len(os.sched_getaffinity(0))}")
+print(f"{B} x 1080p JPEG stills, quality {Q}, restart interval {RST} MCU rows, FRP_JPEG_HOST_HUFFMAN={os.environ.get('FRP_JPEG_HOST_HUFFMAN', '')}: {sum(map(len, jpegs)) / B / 1e3:.0f} kB each; host threads available: {len(os.sched_getaffinity(0))}")
 eng = native.Engine(0, max_batch=B, max_faces=10, max_h=1080, max_w=1920)
 stage = eng.host_frames(B, 1080, 1920)
 
