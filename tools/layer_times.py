@@ -73,17 +73,18 @@ def main():
         tot += d
         tot_gap += gap
         name = r["Kernel_Name"]
-        if "conv_mfma" in name or "conv3x3_rows" in name or "conv3x3_lean" in name or "conv3x3_wino" in name:
+        if "conv_mfma" in name or "conv3x3_rows" in name or "conv3x3_lean" in name or "conv3x3_wino" in name or "conv3x3_c64" in name:
             l, h, w, fl, by = next(convs)
             cfg = re.search(r"<(\d+), (\d+),", name)
             wino = "conv3x3_wino" in name
+            c64 = "conv3x3_c64" in name
             # what this launch cannot beat on this device: its FLOPs at the k-loop's own rate (1.25 PFLOP/s)
             # or its algorithmic bytes at 4.5 TB/s (the best streaming rate measured here), whichever is longer
             bound = max(fl / 1.25e9, by / 4.5e6)
             bounds.append((d, bound))
             print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
                   f"{d:8.1f} us  gap {gap:6.1f}  {fl / d / 1e6:7.1f} TF  {by / d / 1e3:7.1f} GB/s  x{d / bound:4.2f} of "
-                  f"{'mfma' if fl / 1.25e9 >= by / 4.5e6 else 'hbm '} bound  " + (("winograd F(2,3), 8x30-pixel tiles x 128" if "wino2_kernel<32>" in name else "winograd F(2,3) 256x128") if wino else f"tile {cfg.group(1)}x{cfg.group(2)}"))
+                  f"{'mfma' if fl / 1.25e9 >= by / 4.5e6 else 'hbm '} bound  " + (("winograd F(2,3), 8x30-pixel tiles x 128" if "wino2_kernel<32>" in name else "winograd F(2,3) 256x128") if wino else ("64 -> 64 kernel, 8x32-pixel tiles, weights in registers" if c64 else f"tile {cfg.group(1)}x{cfg.group(2)}")))
         else:
             print(f"{name[:57]:57s} grid {r['Grid_Size_X']:>9s} {d:8.1f} us  gap {gap:6.1f}")
     print(f"sum of kernels {tot:.1f} us, sum of gaps {tot_gap:.1f} us, span {(prev_end - t0) / 1e3:.1f} us")
