@@ -60,7 +60,15 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0
 
 
-PMC_SUMMARY = os.path.join("profiles", "r4", "pmc_traffic.json")
+def _pmc_summary():
+    """The newest committed PMC summary (profiles/r<N>/pmc_traffic.json)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_traffic.json")),
+                   key=lambda p: int(os.path.basename(os.path.dirname(p))[1:]))
+    return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", "pmc_traffic.json")
+
+
+PMC_SUMMARY = _pmc_summary()
 
 
 def pmc_conv_traffic_per_launch(launches_per_step):
@@ -778,7 +786,7 @@ def main():
                        "stage_ms_per_step": {k[3:]: round(ctr[k] / args.steps, 3) for k in
                                              ("ms_preprocess", "ms_det_conv", "ms_decode", "ms_align", "ms_emb_conv",
                                               "ms_l2norm", "ms_match")}},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_lean_kernel + conv3x3_wino2_kernel + conv_mfma_kernel + stem12_u8_kernel + emb_stem_kernel (conv family, all detector+embedder launches; FLOPs = the direct convolution's algorithmic count, also for the Winograd launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_lean_kernel + conv3x3_wino2_kernel + conv3x3_c64_kernel + conv_mfma_kernel + stem12_u8_kernel + emb_stem_kernel (conv family, all detector+embedder launches; FLOPs = the direct convolution's algorithmic count, also for the Winograd launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_conv_traffic_per_launch(launches // max(1, args.steps)),

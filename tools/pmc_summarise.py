@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import frp_amd_loader  # noqa: E402,F401
 from frp_amd import native  # noqa: E402
 
-FAMILIES = ["conv3x3_lean_kernel", "conv3x3_wino", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel", "stem_u8_kernel", "gather_logits_kernel", "topk_rows_kernel", "preprocess_kernel", "decode_nms_kernel", "align_kernel",
-            "match_kernel", "l2norm", "compact_faces", "chips_to_blob"]
+FAMILIES = ["conv3x3_lean_kernel", "conv3x3_wino", "conv3x3_c64_kernel", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel", "stem_u8_kernel", "gather_logits_kernel", "topk_rows_kernel", "preprocess_kernel", "decode_nms_kernel", "align_kernel",
+            "match_kernel", "match_top1_kernel", "l2norm", "compact_faces", "chips_to_blob"]
 SKIP = ["normalize_rows_kernel", "fill_random", "mfma_peak"]
 
 
@@ -67,7 +67,7 @@ def main():
         n = max(n, n2)
         kernels[fam] = {"launches": n, "fetch_KB_raw_sum": round(fkb), "write_KB_sum": round(wkb),
                         "hbm_bytes_per_launch_corrected": round((2 * fkb + wkb) * 1024 / max(n, 1))}
-    conv = {k: sum(kernels.get(f, {}).get(k, 0) for f in ("conv3x3_lean_kernel", "conv3x3_wino", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel"))
+    conv = {k: sum(kernels.get(f, {}).get(k, 0) for f in ("conv3x3_lean_kernel", "conv3x3_wino", "conv3x3_c64_kernel", "conv3x3_rows_kernel", "conv_mfma_kernel", "stem12_u8_kernel", "emb_stem_kernel"))
             for k in ("fetch_KB_raw_sum", "write_KB_sum")}
     doc = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `bench.py --steps 2 "
