@@ -537,6 +537,10 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
         p.w = p.wino_w;
         return launch_conv3x3_wino(p, stream);
     }
+    // 3x3 stride-2 layers: row patches with shared neighbour entries (conv3x3_s2.hip).  OPT-IN (dbg bit 2048: FRP_S2=1 in the engine,
+    // flags bit 21 of frp_conv2d_nhwc): on the headline shapes it measures 9-13 % SLOWER than this kernel's per-tap images
+    // (profiles/r5/s2_probe.txt)
+    if ((p.dbg & 2048) && !(p.dbg & 1) && !few && conv3x3_s2_eligible(p)) return launch_conv3x3_s2(p, stream);
     // 64 -> 64 layers on large maps: weights in registers, 2-D tiles (conv3x3_c64.hip; dbg bit 512 / FRP_NO_C64=1: the row-patch
     // kernel instead - A/B runs; bit-identical results either way)
     {

@@ -375,6 +375,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
     // the tile count of each launch (A/B runs, tests that pin a kernel family)
     const char* sm_env = getenv("FRP_SMALL_M");
     const int small_m = !sm_env ? 0 : (sm_env[0] == '0' ? -1 : 1);
+    const bool s2_optin = getenv("FRP_S2") != nullptr;        // the opt-in stride-2 row-patch kernel (conv3x3_s2.hip; A/B runs, its pipeline test)
     // both detector stems in one kernel (the stem1 map never reaches HBM); FRP_NO_FUSED_STEM12=1 keeps
     // stem1 (fused with the u8 normalisation) and stem2 (generic conv) apart for A/B runs
     if (stem && stem12_fusable(net) && (stem->Hc % 4) == 0 && (stem->Wc % 4) == 0 && !getenv("FRP_NO_FUSED_STEM12")) {
@@ -464,6 +465,7 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.n_dev = n_dev;
         p.n_cu = h->n_cu;
         p.small_m = small_m;
+        if (s2_optin) p.dbg |= 2048;
         p.wino_wide_only = &net == &h->det ? 1 : 0;
         {
             const size_t oi = (size_t)(&op - net.ops.data());
@@ -2311,7 +2313,7 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.out = dout.p;
             p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
-            p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0);      // (bit 20: not the 64 -> 64 kernel)      // kernel A/B switches (tests: 1 = generic kernel instead of the
+            p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0);      // (bit 20: not the 64 -> 64 kernel; bit 21: the opt-in stride-2 row-patch kernel)      // kernel A/B switches (tests: 1 = generic kernel instead of the
                                                                                 // row-patch one; flags bit 19 = dbg 256: the Winograd kernel's 2-D tiles, lab build)
             // flags bit 17 / 18: quarter tiles always / never (default: by the tile count, conv_common.h: conv_small_m)
             p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || want_wino) ? -1 : 0;
@@ -2420,7 +2422,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
             if (!(flags & FRP_FLAG_OUT_FP8)) p.out2 = dr.p;   // conv2-style: fp16 out + fp8 copy (residual buffer doubles as the copy target when unused)
             if (with_res) p.out2 = nullptr;
         }
-        p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0);      // (bit 20: not the 64 -> 64 kernel)
+        p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0);      // (bit 20: not the 64 -> 64 kernel)
         p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
         bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu, with_res != 0));

@@ -72,6 +72,9 @@ hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // st
 // 3x3 stride-1 64 -> 64 layers on large maps (conv3x3_c64.hip): weights resident in registers, 2-D pixel tiles, one barrier per tile
 bool conv3x3_c64_eligible(const ConvParams& p);
 hipError_t launch_conv3x3_c64(const ConvParams& p, hipStream_t stream);
+// 3x3 stride-2 layers (conv3x3_s2.hip): row patches whose left / right neighbour entries are shared by consecutive output pixels
+bool conv3x3_s2_eligible(const ConvParams& p);
+hipError_t launch_conv3x3_s2(const ConvParams& p, hipStream_t stream);
 // Winograd F(2,3) along the image rows (conv3x3_wino.hip): eligibility of a shape (`p` with launch_conv()'s derived fields),
 // the same from the static layer geometry, the size of a layer's weight image, the launch (p.w = the image)
 bool conv3x3_wino_eligible(const ConvParams& p);

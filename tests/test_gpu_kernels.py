@@ -160,6 +160,52 @@ def test_conv_c64_vs_fp32_reference_and_generic_kernel(engine, case, monkeypatch
         assert np.array_equal(out.view(np.uint16), again.view(np.uint16))
 
 
+S2_CASES = [
+    # N, H, W, Cin, Cout, act
+    (3, 28, 28, 64, 128, 1),        # 14-wide output rows: 18 image rows begin inside a tile
+    (2, 136, 240, 64, 128, 1),      # detector layer2.0.conv1 shape class: ReLU, 120-wide rows
+    (5, 14, 14, 256, 256, 0),       # 7-wide rows (the narrowest the kernel takes), two cout tiles, less than one pixel tile
+    (9, 56, 56, 128, 128, 0),       # IResNet layer2.0.conv2 shape class (without its shortcut segment)
+    (40, 28, 28, 256, 256, 0),      # ... layer3.0.conv2
+    (3, 30, 22, 128, 256, 1),       # odd output sizes (15 x 11), ragged last tile
+    (2, 68, 120, 256, 256, 1),      # detector layer4.0.conv1
+    (6, 14, 14, 512, 512, 0),       # 16 channel blocks, four cout tiles
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv_stride2_row_patch_kernel_vs_fp32_reference_and_generic_kernel(engine, case):
+    """the stride-2 kernel (row patches with shared left / right neighbour entries, conv3x3_s2.hip) against the fp32 reference (the
+    direct kernels' bar) and against the generic kernel (dbg 1), from which it differs in the k order (32- instead of 64-channel
+    blocks) and therefore in the last bits of the fp32 sums: within 2 fp16 ulps of the output scale, most elements identical;
+    12 more launches return the bits of the first (its rings run two steps ahead across tile boundaries)."""
+    N, H, W, Cin, Cout, act = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float16)
+    bias = rng.standard_normal((Cout,)).astype(np.float32) * 0.3
+    kw = dict(stride=2, act=act)
+    S2 = TILES_DEFAULT | 0x200000          # (the kernel is opt-in: flags bit 21 / FRP_S2=1 - it measures slower than the per-tap images)
+    out = engine.conv2d(x, w, bias, flags=S2, **kw)
+    generic = engine.conv2d(x, w, bias, flags=TILES_DEFAULT | (1 << 8), **kw)
+    assert out.shape == generic.shape == (N, H // 2, W // 2, Cout)
+    scale = max(1.0, float(np.abs(generic.astype(np.float32)).max()))
+    ulp = float(np.spacing(np.float16(scale)))
+    d = np.abs(out.astype(np.float32) - generic.astype(np.float32))
+    worst = np.unravel_index(int(d.argmax()), d.shape)
+    assert d.max() <= 2 * ulp, f"max |diff| {d.max():.4g} = {d.max() / ulp:.1f} ulps of {scale:.3g} at (n, y, x, c) = {worst}"
+    assert (out.view(np.uint16) == generic.view(np.uint16)).mean() >= 0.9
+    sub = slice(0, min(N, 3))
+    ref = _conv_ref(x[sub], w, bias, 2, act, None, None, 0)
+    assert np.abs(out[sub].astype(np.float32) - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    for _ in range(12):
+        again = engine.conv2d(x, w, bias, flags=S2, **kw)
+        assert np.array_equal(out.view(np.uint16), again.view(np.uint16))
+    # the two kernels differ in the k order: somewhere in a tensor this size a last bit does (i.e. the opt-in bit did select the kernel)
+    if out.size >= 1 << 18:
+        assert not np.array_equal(out.view(np.uint16), generic.view(np.uint16))
+
+
 # cases the quarter-tile configurations cover with the k order of the default tiles (fp16 output, no split-K)
 QUARTER_CASES = [c for c in CONV_CASES if c[3] % 64 == 0 and not (c[9] & 2)] + [
     (36, 14, 14, 256, 256, 3, 1, 2, True, 1),    # 36 faces at IResNet stage 3 (config 4's operating point): 56 default tiles
@@ -879,6 +925,31 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
     assert np.array_equal(e, out["separate", 4][0]) and engine.counters()["emb_conv_launches"] == out["separate", 4][1]
     engine.load_weights(blob)
     assert np.abs(out["fused", 70][0][:4] - out["fused", 4][0]).max() < 1e-6     # (same family, other tile sizes; the FC's split-K factor differs)
+
+
+def test_stride2_row_patch_kernel_in_the_embedder_with_the_shortcut_segments(engine, monkeypatch):
+    """the opt-in stride-2 kernel (FRP_S2=1) inside IResNet: its three eligible strided convs (128, 256, 512 channels) carry the block's
+    1x1 shortcut as a second K segment at the centre tap (ConvParams::x2 - the path the single-conv hook cannot reach).  Default
+    tiles for both runs (FRP_SMALL_M=0: 70 faces would otherwise put stage 3 / 4 on quarter tiles, which the kernel does not
+    have).  Equal to the per-tap kernel to 1 - cos <= 1e-5, not the same bits (another k order: the kernel did run), as close to
+    the fp32 oracle."""
+    rng = np.random.default_rng(23)
+    chips = rng.integers(0, 256, size=(70, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (2, 2, 2, 2))
+    monkeypatch.setenv("FRP_SMALL_M", "0")
+    engine.load_weights(blob)
+    base = engine.embed_aligned(chips)
+    monkeypatch.setenv("FRP_S2", "1")
+    s2 = engine.embed_aligned(chips)
+    again = engine.embed_aligned(chips)
+    monkeypatch.delenv("FRP_S2")
+    assert np.array_equal(engine.embed_aligned(chips), base)
+    assert np.array_equal(s2, again)
+    assert not np.array_equal(s2, base)
+    assert 1 - (s2 * base).sum(1).min() <= 1e-5
+    ref = onet.emb_forward(raw, onet.emb_blob(chips[:4]))
+    assert (s2[:4] * ref).sum(1).min() > 1 - 1e-3
+    print("1 - cos: stride-2 row-patch kernel vs per-tap kernel", 1 - (s2 * base).sum(1).min(), "vs oracle", 1 - (s2[:4] * ref).sum(1).min())
 
 
 def test_gallery_reserve_commit_zero_copy_import(engine):
