@@ -26,10 +26,9 @@
 
 namespace frp {
 
-#define C64_TH 8
-#define C64_TW 32
-#define C64_PW (C64_TW + 2)                 // patch columns
-#define C64_ROWS ((C64_TH + 2) * C64_PW)    // 340 patch pixels
+// Tile geometry (template parameter TW): 32 columns x 8 rows (halo'd patch 10 x 34 = 340 pixels; a pixel block of the MFMA = one tile
+// row) or 16 x 16 (patch 18 x 18 = 324; a pixel block = two tile rows of 16) - whichever wastes fewer tile pixels on the map.
+#define C64_ROWS_MAX 340
 #define C64_PITCH 144                       // LDS bytes per patch pixel: 128 + one 16-byte pad slot.  9 sixteen-byte slots per pixel
                                             // make consecutive pixels walk all 16 slot positions of the 256-byte bank row (9 is odd), so
                                             // a ds_read_b128's 16-lane groups are conflict-free WITHOUT an xor swizzle - and without
@@ -37,6 +36,7 @@ namespace frp {
                                             // immediate: no vector instruction in the k-loop (with the xor layout of the other kernels a
                                             // tile cost 72 v_xor + 90 address operations per wave, and the loop was VALU-issue-bound)
 #define C64_PIECES 48                       // LDS-DMA pieces per patch (1 KiB = 7.1 pixels each; 340 x 144 B = 47.8 KiB: six per wave)
+static_assert(C64_ROWS_MAX * 9 <= C64_PIECES * 64, "patch slots");
 #define C64_BUF (C64_PIECES * 1024)
 #define C64_NBUF 3
 #define C64_OFF_PAR (C64_NBUF * C64_BUF)
@@ -46,8 +46,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Specialised at compile time on (activation, residual, border-class bias): with the flags as run-time values the epilogue was a
 // chain of ~90 uniform branches and the register allocator spilled eleven registers, each reload a vmcnt(0) in the tile loop.
-template <int ACT, bool RES, bool BORDER>
+template <int ACT, bool RES, bool BORDER, int C64_TW = 32>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
+    constexpr int C64_TH = 256 / C64_TW;              // 8 or 16 tile rows
+    constexpr int C64_RB = 32 / C64_TW;               // tile rows per 32-pixel block: 1 or 2
+    constexpr int C64_PW = C64_TW + 2;                // patch columns
+    constexpr int C64_ROWS = (C64_TH + 2) * C64_PW;   // patch pixels
+    static_assert((C64_TW == 32 || C64_TW == 16) && C64_ROWS <= C64_ROWS_MAX, "tile geometry");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
     int N = p.N;
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
     auto issue_piece = [&](const Patch& q, int j, int slot) {
         const int sl = (wave + 8 * j) * 64 + lane_e;
         const int R = (sl * 7282) >> 16, chunk = sl - 9 * R;               // sl / 9, sl % 9 (exact for sl < 3072)
-        const int py = (R * 241) >> 13, px = R - py * C64_PW;              // R / 34, R % 34 (exact for R < 384)
+        const int py = C64_TW == 32 ? (R * 241) >> 13 : (R * 3641) >> 16;  // R / 34, R / 18 (exact for R < 384)
+        const int px = R - py * C64_PW;
         const int y = q.y0 + py, x = q.x0 + px;
         const bool ok = q.live && R < C64_ROWS && chunk < 8 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         dma16(xrsrc, smem + slot * C64_BUF + (wave + 8 * j) * 1024, ok ? (unsigned)(q.base + (py * p.W + px) * 128 + chunk * 16) : CONV_OOB);
@@ -129,9 +135,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         for (int j = 0; j < 6; ++j) issue_piece(q, j, slot);
     };
 
-    // ---------------- fragment addresses: pixel block b = tile row 2 wave_p + b, lane = column fr; tap (kh, kw), slice kk reads patch
-    // pixel (row + kh, fr + kw), chunk 2 kk + fh: the block's base + the immediate ((kh * 34 + kw) * 144 + kk * 32)
-    const int fbase = ((2 * wave_p) * C64_PW + fr) * C64_PITCH + fh * 16;
+    // ---------------- fragment addresses: pixel block b = tile rows RB (2 wave_p + b) .. + RB - 1, lane = (row fr / TW, column fr % TW); tap
+    // (kh, kw), slice kk reads patch pixel (row + kh, column + kw), chunk 2 kk + fh: the block's base + the immediate
+    // ((kh * PW + kw) * 144 + kk * 32)
+    // 16-column tiles: WHICH 16 lanes of a block take its first row is chosen to match ds_read_b128's lane groups ({0-3, 12-15, 20-27} and
+    // {4-11, 16-19, 28-31} of a half-wave are serviced together): one group = 16 consecutive pixels of one patch row, conflict-free like
+    // the 32-column form (lanes 0-15 / 16-31 would put 8 pixels of each row into a group: two bank conflicts per read)
+    const int fq = fr >> 2;
+    const int lrow = C64_TW == 32 ? 0 : (0x96 >> fq) & 1, lcol = C64_TW == 32 ? fr : ((fq >> 1) << 2) | (fr & 3);
+    const int fbase = ((2 * wave_p * C64_RB + lrow) * C64_PW + lcol) * C64_PITCH + fh * 16;
 
     __syncthreads();                           // parameters visible (no LDS-DMA in flight yet: the fence costs nothing)
     issue_patch(t0, 0);
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
 
         const int n = ct / per, r = ct - n * per;
         const int ty = r / tx_n, tx = r - ty * tx_n;
-        const int oy0 = ty * C64_TH + 2 * wave_p, ox = tx * C64_TW + fr;
+        const int oy0 = ty * C64_TH + 2 * wave_p * C64_RB + lrow, ox = tx * C64_TW + lcol;
         const int boff = slot * C64_BUF;
 
         floatx16 acc[2];
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
             const int tap = s >> 2, kk = s & 3;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-                bf[S][b] = *reinterpret_cast<const half8*>(pb + ((b + tap / 3) * C64_PW + tap % 3) * C64_PITCH + kk * 32);
+                bf[S][b] = *reinterpret_cast<const half8*>(pb + ((b * C64_RB + tap / 3) * C64_PW + tap % 3) * C64_PITCH + kk * 32);
         };
         rd(0, 0);
         rd(1, 1);
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         unsigned ooff[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int oy = oy0 + b;
+            const int oy = oy0 + b * C64_RB;
             const bool ok = oy < p.H && ox < p.W;
             const int m = (n * p.H + oy) * p.W + ox;
             ooff[b] = ok ? (unsigned)(m * 128 + wave_c * 64 + fh * 16) : CONV_OOB;
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int oy = oy0 + b;
+            const int oy = oy0 + b * C64_RB;
             int cls = 0;
             if (border) cls = ((oy == 0) ? 0 : (oy == p.H - 1) ? 2 : 1) * 3 + ((ox == 0) ? 0 : (ox == p.W - 1) ? 2 : 1);
             half4 r4[4];
@@ -254,6 +266,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
 }
 
 static int c64_variant(const ConvParams& p);
+// tile width for a map: the geometry that wastes fewer tile pixels (32 x 8 on a tie: its halo is the smaller share of the DMA)
+static int c64_tile_width(const ConvParams& p, double* fill = nullptr) {
+    double best = 0;
+    int tw_best = 32;
+    for (int tw : {32, 16}) {
+        const int th = 256 / tw;
+        const double f = (double)p.H * p.W / ((double)((p.H + th - 1) / th * th) * (double)((p.W + tw - 1) / tw * tw));
+        if (f > best + 1e-9) { best = f; tw_best = tw; }
+    }
+    if (fill) *fill = best;
+    return tw_best;
+}
+static long c64_tiles(const ConvParams& p, int tw) {
+    const int th = 256 / tw;
+    return (long)p.N * ((p.H + th - 1) / th) * ((p.W + tw - 1) / tw);
+}
 // Shapes the kernel covers (`p` with launch_conv()'s derived fields) - and where it pays: at least two rounds of tiles.
 bool conv3x3_c64_eligible(const ConvParams& p) {
     if (p.KS != 3 || p.stride != 1 || p.Cin != 64 || p.Cout != 64 || p.ksplit != 1 || p.x2 || p.out2) return false;
@@ -262,20 +290,21 @@ bool conv3x3_c64_eligible(const ConvParams& p) {
     if ((long)p.N * p.H * p.W * 128 >= 0x7f000000L) return false;                  // signed 32-bit byte offsets (+ a patch of slack)
     if (!c64_variant(p)) return false;
     if (p.act == FRP_ACT_PRELU && !p.slope) return false;
-    const long ty = (p.H + C64_TH - 1) / C64_TH, tx = (p.W + C64_TW - 1) / C64_TW;
-    const long tiles = (long)p.N * ty * tx;
-    if (tiles < 2L * (p.n_cu > 0 ? p.n_cu : 256)) return false;
-    // where it pays (tools/c64_probe.py, profiles/r5/c64_probe.txt): x1.11 / x1.14 over the row-patch kernel on the detector's 272 x 480
-    // maps, whose 32-column tiles are all full; x0.99-1.03 on the embedder's 112 x 112 and 56 x 56 maps, where every fourth / second
-    // tile column is half empty - those stay on the row-patch kernel (FRP_C64_ALL=1 takes every eligible shape: the parity tests)
+    double fill = 0;
+    const int tw = c64_tile_width(p, &fill);
+    if (c64_tiles(p, tw) < 2L * (p.n_cu > 0 ? p.n_cu : 256)) return false;
+    // where it pays (tools/c64_probe.py, profiles/r5/c64_probe.txt): x1.11 / x1.14 over the row-patch kernel on maps whose tiles are all
+    // full (the detector's 272 x 480 in 32 x 8 tiles, the embedder's 112 x 112 in 16 x 16 tiles); x0.99-1.03 on its 56 x 56 maps, where
+    // either geometry leaves an eighth of the tile pixels empty - those stay on the row-patch kernel (FRP_C64_ALL=1 takes every
+    // eligible shape: the parity tests)
     static const bool all = getenv("FRP_C64_ALL") != nullptr;
-    return all || (double)p.H * p.W >= 0.95 * (double)(ty * C64_TH) * (double)(tx * C64_TW);
+    return all || fill >= 0.95;
 }
 
-template <int ACT, bool RES, bool BORDER>
-static hipError_t launch_c64_cfg(const ConvParams& p, hipStream_t stream) {
+template <int ACT, bool RES, bool BORDER, int TW>
+static hipError_t launch_c64_geo(const ConvParams& p, hipStream_t stream) {
     static bool attr_set[64] = {};
-    auto kern = conv3x3_c64_kernel<ACT, RES, BORDER>;
+    auto kern = conv3x3_c64_kernel<ACT, RES, BORDER, TW>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -285,11 +314,16 @@ static hipError_t launch_c64_cfg(const ConvParams& p, hipStream_t stream) {
     }
     const int ncu = device_cu_count(dev);
     if (ncu <= 0) return hipErrorInvalidDevice;
-    const long tiles = (long)p.N * ((p.H + C64_TH - 1) / C64_TH) * ((p.W + C64_TW - 1) / C64_TW);
+    const long tiles = c64_tiles(p, TW);
     if (tiles <= 0 || tiles > 0x7fffffffL) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(tiles < ncu ? tiles : ncu);       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, stream, p);
     return hipGetLastError();
+}
+
+template <int ACT, bool RES, bool BORDER>
+static hipError_t launch_c64_cfg(const ConvParams& p, hipStream_t stream) {
+    return c64_tile_width(p) == 16 ? launch_c64_geo<ACT, RES, BORDER, 16>(p, stream) : launch_c64_geo<ACT, RES, BORDER, 32>(p, stream);
 }
 
 // the four (activation, residual, border bias) combinations the two networks have on these layers
