@@ -46,13 +46,26 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Specialised at compile time on (activation, residual, border-class bias): with the flags as run-time values the epilogue was a
 // chain of ~90 uniform branches and the register allocator spilled eleven registers, each reload a vmcnt(0) in the tile loop.
-template <int ACT, bool RES, bool BORDER, int C64_TW = 32>
+// STEM (round 5): the launch also computes the embedder's stem conv of its own input patch (ConvParams::stem_x): per tile the chips under
+// the patch (+ one more halo pixel) arrive by LDS-DMA two tiles ahead (one piece per wave), a short MFMA phase turns them into the
+// 64-channel patch in LDS (and stores the tile's own pixels of that map for the block's shortcut) - the patch of tile t + 1 in the
+// iteration that multiplies tile t, so the one barrier per tile stays and the phase is not exposed between two barriers (as a phase of
+// its own in front of the k-loop the fused launch took as long as the two launches it replaces).  Same instructions on the same operands as emb_stem_kernel and as the unfused k-loop: bit-identical.
+#define C64_CHIP_SLOT 8192                  // chips under a patch: (TH + 4) x (TW + 4) pixels of 16 B <= 512 pixels
+#define C64_OFF_CHIPS (2 * C64_BUF)          // (the patch is double-buffered: the stem phase of tile t + 1 runs beside the k-loop of tile t)
+#define C64_OFF_SW (C64_OFF_CHIPS + 3 * C64_CHIP_SLOT)       // stem weight fragments [cout group][kh][lane] (6 KiB)
+#define C64_OFF_SPAR (C64_OFF_SW + 6 * 1024)                 // stem bias [64], slope [64]
+
+template <int ACT, bool RES, bool BORDER, int C64_TW = 32, bool STEM = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
     constexpr int C64_TH = 256 / C64_TW;              // 8 or 16 tile rows
     constexpr int C64_RB = 32 / C64_TW;               // tile rows per 32-pixel block: 1 or 2
     constexpr int C64_PW = C64_TW + 2;                // patch columns
     constexpr int C64_ROWS = (C64_TH + 2) * C64_PW;   // patch pixels
     static_assert((C64_TW == 32 || C64_TW == 16) && C64_ROWS <= C64_ROWS_MAX, "tile geometry");
+    constexpr int C64_CW = C64_TW + 4, C64_CH = C64_TH + 4;   // chips under a patch (STEM)
+    constexpr int C64_NBLK = (C64_ROWS + 31) / 32;            // 32-pixel blocks of a patch (STEM): 11
+    static_assert(C64_CW * C64_CH <= 512 && C64_NBLK <= 16 && C64_OFF_SPAR + 512 <= C64_OFF_PAR && !(STEM && RES), "stem fusion");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     ConvParams p = p_in;
     int N = p.N;
@@ -91,6 +104,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
     constexpr bool border = BORDER;
     for (int i = t; i < 9 * 64; i += 512) lds_bias[i] = (border || i < 64) ? p.bias[i] : 0.f;
     if (t < 64) lds_slope[t] = (ACT == FRP_ACT_PRELU && p.slope) ? p.slope[t] : 0.f;
+
+    // ---------------- STEM: the stem's A fragments (lane (cout r, half h) of cout group cg, kernel row kh: k' = 8h + j = kw*4 + c, as
+    // emb_stem_kernel builds them in registers - here they wait in LDS, the registers hold this kernel's own 144), bias and slope
+    if (STEM) {
+        if (t < 384) {
+            const int f = t >> 6, l = t & 63, r_ = l & 31, h_ = l >> 5, cg = f / 3, kh = f - cg * 3;
+            const _Float16* w = p.stem_w + (((cg * 32 + r_) * 3 + kh) * 3) * 8;
+            union { uint2 u[2]; u32x4 v; } fw;
+            fw.u[0] = *reinterpret_cast<const uint2*>(w + (2 * h_) * 8);
+            fw.u[1] = h_ ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2*>(w + 8);
+            *reinterpret_cast<u32x4*>(smem + C64_OFF_SW + t * 16) = fw.v;
+        }
+        if (t < 64) {
+            reinterpret_cast<float*>(smem + C64_OFF_SPAR)[t] = p.stem_bias[t];
+            reinterpret_cast<float*>(smem + C64_OFF_SPAR)[64 + t] = p.stem_slope[t];
+        }
+    }
 
     // ---------------- this wave's weights: 32 couts x K = 576 as 36 MFMA A fragments (k-slice s = tap * 4 + kk: channels 16 kk + 8 fh .. + 7)
     const int wave_p = wave >> 1, wave_c = wave & 1;
@@ -145,16 +175,108 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
     const int lrow = C64_TW == 32 ? 0 : (0x96 >> fq) & 1, lcol = C64_TW == 32 ? fr : ((fq >> 1) << 2) | (fr & 3);
     const int fbase = ((2 * wave_p * C64_RB + lrow) * C64_PW + lcol) * C64_PITCH + fh * 16;
 
+    // ---------------- STEM: the chips under a tile's patch, one LDS-DMA piece per wave: slot pixel 64 wave + lane = (cy, cx) of the
+    // (TH + 4) x (TW + 4) block whose origin lies two pixels up and left of the tile; outside the chip: zeros (the stem's padding)
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(STEM ? p.stem_x : p.x), 0, STEM ? (unsigned)((long)p.N * p.H * p.W * 16) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(STEM ? (void*)p.stem_out : p.out, 0, STEM ? o_bytes : 0u, 0x00020000);
+    auto issue_chips = [&](int tile, int cslot) {
+        const Patch q = patch_of(tile);                          // (y0, x0: the patch origin = tile origin - 1)
+        const int sl = wave * 64 + lane_e;
+        const int cy = C64_TW == 32 ? (sl * 1821) >> 16 : (sl * 3277) >> 16, cx = sl - cy * C64_CW;     // sl / 36, sl / 20 (exact for sl < 512)
+        const int y = q.y0 - 1 + cy, x = q.x0 - 1 + cx;
+        const bool ok = q.live && cy < C64_CH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const int n_ = q.live ? tile / per : 0;
+        dma16(crsrc, smem + C64_OFF_CHIPS + cslot * C64_CHIP_SLOT + wave * 1024, ok ? (unsigned)(((n_ * p.H + y) * p.W + x) * 16) : CONV_OOB);
+    };
+    const int n_myblk = (wave + 8 < C64_NBLK) ? 2 : 1;           // patch blocks of this wave in the stem phase (wave-uniform)
+
+    // ---- stem phase: the 64-channel patch of `tile` from its chips (slot cslot of the chips ring) into patch buffer pbuf
+    auto stem_phase = [&](int tile, int cslot, int pbuf) __attribute__((always_inline)) {
+            const Patch cq = patch_of(tile);
+            const int n_ = tile / per;
+            const unsigned char* cs = smem + C64_OFF_CHIPS + cslot * C64_CHIP_SLOT;
+            const float* sb = reinterpret_cast<const float*>(smem + C64_OFF_SPAR);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                if (bi == 1 && n_myblk < 2) break;
+                const int R = (wave + 8 * bi) * 32 + fr;
+                const bool valid = R < C64_ROWS;
+                const int Rc = valid ? R : 0;
+                const int py = C64_TW == 32 ? (Rc * 241) >> 13 : (Rc * 3641) >> 16, px = Rc - py * C64_PW;
+                floatx16 sacc[2];
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[cg][e] = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    // lane half h: chips (row py + kh, columns px + 2h, px + 2h + 1), 4 of their 8 halfwords each (R, G, B, 0): kw = 2h, 2h + 1
+                    const unsigned char* src = cs + ((py + kh) * C64_CW + px + 2 * fh) * 16;
+                    union { uint2 u[2]; half8 v; } bfr;
+                    bfr.u[0] = *reinterpret_cast<const uint2*>(src);
+                    bfr.u[1] = *reinterpret_cast<const uint2*>(src + 16);
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        const half8 wa = *reinterpret_cast<const half8*>(smem + C64_OFF_SW + ((cg * 3 + kh) * 64 + lane) * 16);
+                        sacc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bfr.v, sacc[cg], 0, 0, 0);
+                    }
+                }
+                const int y = cq.y0 + py, x = cq.x0 + px;
+                const bool inimg = valid && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                // a pixel of the tile itself: stored (stem_even_only: if a stride-2 reader will ask for it)
+                const bool mine = inimg && py >= 1 && py <= C64_TH && px >= 1 && px <= C64_TW && !(p.stem_even_only && ((y | x) & 1));
+                const unsigned goff = mine ? (unsigned)(((n_ * p.H + y) * p.W + x) * 128 + fh * 16) : CONV_OOB;
+                unsigned char* prow = smem + pbuf * C64_BUF + R * C64_PITCH + fh * 16;
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    union { half4 hv; unsigned u[2]; } pk[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const floatx4 b4 = *reinterpret_cast<const floatx4*>(sb + 32 * cg + 8 * g + 4 * fh);
+                        const floatx4 s4 = *reinterpret_cast<const floatx4*>(sb + 64 + 32 * cg + 8 * g + 4 * fh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = sacc[cg][4 * g + e] + b4[e];
+                            pk[g].hv[e] = (_Float16)(v > 0.f ? v : v * s4[e]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
+                        swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
+                        u32x4 o = {pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]};     // couts 32 cg + 16 q + 8 fh .. + 7
+                        __builtin_amdgcn_raw_buffer_store_b128(o, srsrc, goff + cg * 64 + q * 32, 0, 0);
+                        if (!inimg) o = u32x4{0u, 0u, 0u, 0u};                  // the conv's zero padding, not the stem of padded chips
+                        if (valid) *reinterpret_cast<u32x4*>(prow + cg * 64 + q * 32) = o;
+                    }
+                }
+            }
+    };
+
     __syncthreads();                           // parameters visible (no LDS-DMA in flight yet: the fence costs nothing)
-    issue_patch(t0, 0);
-    issue_patch(t0 + tstep, 1);
+    if (STEM) {
+        issue_chips(t0, 0);
+        issue_chips(t0 + tstep, 1);
+        wait_vmcnt<1>();
+        __builtin_amdgcn_s_barrier();          // every wave's piece of the first tile's chips has landed
+        stem_phase(t0, 0, 0);
+    } else {
+        issue_patch(t0, 0);
+        issue_patch(t0 + tstep, 1);
+    }
     constexpr bool has_res = RES;
 
-    int slot = 0;
-    for (int ct = t0; ct < t1; ct += tstep) {
+    int slot = 0, it = 0;
+    for (int ct = t0; ct < t1; ct += tstep, ++it) {
         // tile ct has landed: behind its pieces in the in-order counter sit the next tile's six pieces and - from the second tile
         // on - the four stores of the last epilogue (unconditional: the count is exact)
-        if (ct == t0) wait_vmcnt<6>();
+        if (STEM) {
+            // the chips of tile ct + 1 (consumed below) have landed once only this wave's stores behind them may be pending: 4 per patch
+            // block of the stem phase that followed their issue + - from the second tile on - the last epilogue's 4
+            if (ct == t0) { if (n_myblk == 2) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
+            else if (n_myblk == 2) wait_vmcnt<12>();
+            else wait_vmcnt<8>();
+        } else if (ct == t0) wait_vmcnt<6>();
         else if (has_res) wait_vmcnt<14>();    // (the epilogue's four residual loads sit in front of its stores)
         else wait_vmcnt<10>();
         retire_lds_reads();
@@ -162,6 +284,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         asm volatile("" : "+v"(lane_e));
         int nslot = slot + 2;
         nslot = nslot >= C64_NBUF ? nslot - C64_NBUF : nslot;
+        if (STEM) {
+            issue_chips(ct + 2 * tstep, nslot);                       // into the slot the previous iteration's stem phase read
+            // the next tile's patch: waves 0-3 build their blocks BEFORE this tile's k-loop, waves 4-7 behind its epilogue - the two waves of
+            // a SIMD (w and w + 4) are then in opposite phases, one converting and packing while the other multiplies (all eight in the
+            // same order: +2.4 us per 5 us tile, the fused launch as long as the two it replaces)
+            if (wave < 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
+        }
         // the patch two tiles ahead goes out BETWEEN the MFMAs below (its address arithmetic hides under matrix time; it has two
         // tiles to land); past the end: zero-fill into a slot nobody reads
         const Patch nq = patch_of(ct + 2 * tstep);
@@ -169,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         const int n = ct / per, r = ct - n * per;
         const int ty = r / tx_n, tx = r - ty * tx_n;
         const int oy0 = ty * C64_TH + 2 * wave_p * C64_RB + lrow, ox = tx * C64_TW + lcol;
-        const int boff = slot * C64_BUF;
+        const int boff = STEM ? (it & 1) * C64_BUF : slot * C64_BUF;
 
         floatx16 acc[2];
 #pragma unroll
@@ -191,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
             if (s + 2 < 36) rd(s + 2, (s + 2) % 3);
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bf[s % 3][b], acc[b], 0, 0, 0);
-            if (s % 5 == 4 && s / 5 < 6) issue_piece(nq, s / 5, nslot);
+            if (!STEM && s % 5 == 4 && s / 5 < 6) issue_piece(nq, s / 5, nslot);
             __builtin_amdgcn_sched_barrier(0);             // (the slices stay in this order: the compiler pulls the reads next to their MFMAs)
         }
 
@@ -259,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
                 __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[b] + 32 * q, 0, 0);   // couts 32 wave_c + 16 q + 8 fh .. + 7
             }
         }
+        if (STEM && wave >= 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
         slot = slot + 1 == C64_NBUF ? 0 : slot + 1;
     }
     // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
@@ -290,6 +420,8 @@ bool conv3x3_c64_eligible(const ConvParams& p) {
     if ((long)p.N * p.H * p.W * 128 >= 0x7f000000L) return false;                  // signed 32-bit byte offsets (+ a patch of slack)
     if (!c64_variant(p)) return false;
     if (p.act == FRP_ACT_PRELU && !p.slope) return false;
+    if (p.stem_x && (c64_variant(p) != 3 || !p.stem_w || !p.stem_bias || !p.stem_slope || !p.stem_out || (long)p.N * p.H * p.W * 16 >= 0x7f000000L))
+        return false;
     double fill = 0;
     const int tw = c64_tile_width(p, &fill);
     if (c64_tiles(p, tw) < 2L * (p.n_cu > 0 ? p.n_cu : 256)) return false;
@@ -301,10 +433,10 @@ bool conv3x3_c64_eligible(const ConvParams& p) {
     return all || fill >= 0.95;
 }
 
-template <int ACT, bool RES, bool BORDER, int TW>
+template <int ACT, bool RES, bool BORDER, int TW, bool STEM = false>
 static hipError_t launch_c64_geo(const ConvParams& p, hipStream_t stream) {
     static bool attr_set[64] = {};
-    auto kern = conv3x3_c64_kernel<ACT, RES, BORDER, TW>;
+    auto kern = conv3x3_c64_kernel<ACT, RES, BORDER, TW, STEM>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
@@ -319,6 +451,16 @@ static hipError_t launch_c64_geo(const ConvParams& p, hipStream_t stream) {
     const unsigned grid = (unsigned)(tiles < ncu ? tiles : ncu);       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C64_LDS, stream, p);
     return hipGetLastError();
+}
+
+// maps on which the launch of the embedder's first 64 -> 64 conv also computes the stem in front of it (frp_api.cpp: run_net): where the
+// kernel is routed anyway
+bool conv3x3_c64_fuses_stem(int N, int H, int W, int n_cu) {
+    ConvParams q{};
+    q.N = N; q.H = H; q.W = W; q.n_cu = n_cu;
+    double fill = 0;
+    const int tw = c64_tile_width(q, &fill);
+    return (long)N * H * W * 128 < 0x7f000000L && c64_tiles(q, tw) >= 2L * (n_cu > 0 ? n_cu : 256) && fill >= 0.95;
 }
 
 template <int ACT, bool RES, bool BORDER>
@@ -340,7 +482,11 @@ hipError_t launch_conv3x3_c64(const ConvParams& p, hipStream_t stream) {
     switch (c64_variant(p)) {
         case 1: return launch_c64_cfg<FRP_ACT_RELU, false, false>(p, stream);
         case 2: return launch_c64_cfg<FRP_ACT_RELU, true, false>(p, stream);
-        case 3: return launch_c64_cfg<FRP_ACT_PRELU, false, true>(p, stream);
+        case 3:
+            if (p.stem_x)
+                return c64_tile_width(p) == 16 ? launch_c64_geo<FRP_ACT_PRELU, false, true, 16, true>(p, stream)
+                                               : launch_c64_geo<FRP_ACT_PRELU, false, true, 32, true>(p, stream);
+            return launch_c64_cfg<FRP_ACT_PRELU, false, true>(p, stream);
         case 4: return launch_c64_cfg<FRP_ACT_NONE, true, false>(p, stream);
         default: return hipErrorInvalidValue;
     }

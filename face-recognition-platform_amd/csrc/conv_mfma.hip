@@ -541,6 +541,8 @@ hipError_t launch_conv(const ConvParams& in, hipStream_t stream) {
     // flags bit 21 of frp_conv2d_nhwc): on the headline shapes it measures 9-13 % SLOWER than this kernel's per-tap images
     // (profiles/r5/s2_probe.txt)
     if ((p.dbg & 2048) && !(p.dbg & 1) && !few && conv3x3_s2_eligible(p)) return launch_conv3x3_s2(p, stream);
+    // the embedder's stem fused into the conv behind it: only conv3x3_c64.hip does that (the caller asked conv3x3_c64_fuses_stem first)
+    if (p.stem_x) return (p.small_m <= 0 && conv3x3_c64_eligible(p)) ? launch_conv3x3_c64(p, stream) : hipErrorInvalidValue;
     // 64 -> 64 layers on large maps: weights in registers, 2-D tiles (conv3x3_c64.hip; dbg bit 512 / FRP_NO_C64=1: the row-patch
     // kernel instead - A/B runs; bit-identical results either way)
     {

@@ -403,6 +403,9 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         first = false;
     }
     // embedder stem (chips NHWC8 -> 3x3 s1 3->64 + PReLU): dedicated kernel; FRP_NO_EMB_STEM=1 keeps the generic one
+    bool fuse_stem = false, fuse_even_only = false;
+    size_t fuse_op = 0;
+    EmbStemParams fused{};
     if (!stem && !net.ops.empty()) {
         const frp_conv_op& a = net.ops[0];
         if (a.in_buf == net.in_buf && a.cin == 8 && (a.real_ch & 0xffff) == 3 && a.cout == 64 && a.ksize == 3 && a.stride == 1 &&
@@ -415,11 +418,40 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
             ep.slope = (const float*)(wbase + a.slope_off);
             ep.out = (_Float16*)net.bufs[a.out_buf].p;
             ep.n_dev = n_dev;
-            hipError_t e = launch_emb_stem(ep, h->stream);
-            if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_emb_stem: ") + hipGetErrorString(e));
+            // ... and where the conv behind it runs on the 64 -> 64 kernel (conv3x3_c64.hip), that launch computes the stem of its own
+            // input patch from the chips: the 64-channel map is written once (the block's shortcut reads it) and never read back by
+            // the conv; one launch fewer.  FRP_NO_STEM_FUSE=1: the two launches (A/B runs; the results are the same bits)
+            // (the next op that launches: the block's shortcut conv in between rides in a later k-loop - kc_skip - and reads the map then)
+            size_t nb = 1;
+            while (nb < net.ops.size() && nb < net.kc_skip.size() && net.kc_skip[nb]) ++nb;
+            if (nb < net.ops.size() && !getenv("FRP_NO_STEM_FUSE") && small_m <= 0) {
+                const frp_conv_op& b = net.ops[nb];
+                const bool plain = !(b.flags & ~FRP_FLAG_BORDER_BIAS) && (b.flags & FRP_FLAG_BORDER_BIAS) && b.out2_buf < 0 && b.res_buf < 0;
+                const bool chained = !(nb < net.kc_src.size() && net.kc_src[nb] >= 0);
+                fuse_stem = plain && chained && b.in_buf == a.out_buf && b.out_buf != a.out_buf && b.cin == 64 && b.cout == 64 && b.ksize == 3 &&
+                            b.stride == 1 && b.act == FRP_ACT_PRELU && b.slope_off >= 0 && conv3x3_c64_fuses_stem(batch, H, W, h->n_cu);
+                fuse_op = nb;
+                // who else reads the stem's map?  Only shortcut convs (1x1, stride 2) that ride in a later k-loop: then a quarter of its
+                // pixels is all that has to reach HBM
+                fuse_even_only = true;
+                for (size_t j = 1; j < net.ops.size(); ++j) {
+                    const frp_conv_op& o = net.ops[j];
+                    if (j == nb || (o.in_buf != a.out_buf && o.res_buf != a.out_buf)) continue;
+                    const bool shortcut = j < net.kc_skip.size() && net.kc_skip[j] && o.in_buf == a.out_buf && o.res_buf != a.out_buf &&
+                                          o.ksize == 1 && o.stride == 2;
+                    if (!shortcut) fuse_even_only = false;
+                }
+                if (getenv("FRP_STEM_FULL_MAP")) fuse_even_only = false;          // (A/B runs)
+            }
+            if (fuse_stem) {
+                fused = ep;
+            } else {
+                hipError_t e = launch_emb_stem(ep, h->stream);
+                if (e != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("launch_emb_stem: ") + hipGetErrorString(e));
+                *launches += 1;
+            }
             d[a.out_buf] = {H, W, 64, false};
             *flops += 2.0 * batch * H * W * 9.0 * 3 * 64;
-            *launches += 1;
             skip = 1;
             first = false;
         }
@@ -466,6 +498,10 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         p.n_cu = h->n_cu;
         p.small_m = small_m;
         if (s2_optin) p.dbg |= 2048;
+        if (fuse_stem && opi == fuse_op) {
+            p.stem_x = fused.x; p.stem_w = fused.w; p.stem_bias = fused.bias; p.stem_slope = fused.slope; p.stem_out = fused.out;
+            p.stem_even_only = fuse_even_only ? 1 : 0;
+        }
         p.wino_wide_only = &net == &h->det ? 1 : 0;
         {
             const size_t oi = (size_t)(&op - net.ops.data());

@@ -55,6 +55,16 @@ struct ConvParams {
     int n_workers;          // faces reads every weight once, cold: its k-steps wait for HBM); n_workers: set by the launcher (0 = the whole grid works)
     int small_m;            // quarter tiles (128 pixels x 64 couts, two workgroups per CU): 0 = when the default tiling leaves half
                             // of the CUs idle (conv_common.h: conv_small_m), 1 = always, -1 = never (tests, A/B runs)
+    // fused embedder stem (conv3x3_c64.hip, round 5): this launch is the 3x3 64 -> 64 conv that FOLLOWS the stem - the kernel computes the
+    // stem (3x3, 3 real of 8 channels -> 64, + bias + PReLU) of every patch pixel itself, from the chips, and feeds its MFMAs from LDS: the
+    // 64-channel map is written (for the block's shortcut) but never read back.  `x` is then only the tensor that WOULD have been read.
+    const _Float16* stem_x;     // chips [N,H,W,8] fp16 (R,G,B,0..), or null = no fusion
+    const _Float16* stem_w;     // folded stem weights [64][3][3][8]
+    const float* stem_bias;     // [64]
+    const float* stem_slope;    // [64]
+    _Float16* stem_out;         // [N,H,W,64]: the stem's output, written by this launch
+    int stem_even_only;         // only the pixels (even y, even x) of stem_out are written: its one reader is a 1x1 stride-2 conv (the block's
+                                // shortcut, riding in a later k-loop) - a quarter of the map's bytes
     // derived by launch_conv():
     int pad, Ho, Wo, M, Ktot, nk, cin_shift, n_ptiles, n_ctiles;
     unsigned x_bytes, w_bytes, x2_bytes;   // buffer-descriptor sizes (each < 2 GiB)
@@ -71,6 +81,7 @@ hipError_t launch_conv3x3_rows(const ConvParams& p, hipStream_t stream);   // fi
 hipError_t launch_conv3x3_lean(const ConvParams& p, hipStream_t stream);   // static k-loop generation (conv3x3_lean.hip)
 // 3x3 stride-1 64 -> 64 layers on large maps (conv3x3_c64.hip): weights resident in registers, 2-D pixel tiles, one barrier per tile
 bool conv3x3_c64_eligible(const ConvParams& p);
+bool conv3x3_c64_fuses_stem(int N, int H, int W, int n_cu);   // maps on which the kernel takes the embedder's stem into the launch of the conv behind it
 hipError_t launch_conv3x3_c64(const ConvParams& p, hipStream_t stream);
 // 3x3 stride-2 layers (conv3x3_s2.hip): row patches whose left / right neighbour entries are shared by consecutive output pixels
 bool conv3x3_s2_eligible(const ConvParams& p);

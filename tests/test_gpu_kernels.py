@@ -894,6 +894,7 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
     chips = rng.integers(0, 256, size=(70, 112, 112, 3), dtype=np.uint8)
     raw, blob = get_raw_and_blob((1, 1, 1, 1), (2, 2, 2, 2))
     ref = onet.emb_forward(raw, onet.emb_blob(chips[:4]))
+    monkeypatch.setenv("FRP_NO_STEM_FUSE", "1")        # (the stem fusion of round 5 saves a launch of its own, only next to K-concat: its own test)
     out = {}
     for mode in ("fused", "separate"):
         if mode == "separate":
@@ -925,6 +926,36 @@ def test_shortcut_k_concat_equals_separate_launches(engine, monkeypatch):
     assert np.array_equal(e, out["separate", 4][0]) and engine.counters()["emb_conv_launches"] == out["separate", 4][1]
     engine.load_weights(blob)
     assert np.abs(out["fused", 70][0][:4] - out["fused", 4][0]).max() < 1e-6     # (same family, other tile sizes; the FC's split-K factor differs)
+
+
+def test_embedder_stem_fused_into_the_first_64_channel_conv_is_bit_identical(engine, monkeypatch):
+    """the embedder's stem conv (3 -> 64 + PReLU) computed INSIDE the launch of the 64 -> 64 conv behind it (conv3x3_c64.hip, STEM: the
+    chips under every patch by LDS-DMA, a short MFMA phase writes the 64-channel patch into LDS and the tile's own pixels of the map
+    to HBM for the block's shortcut): the same instructions on the same operands as emb_stem_kernel followed by the unfused conv -
+    embeddings bit for bit those of the two launches (FRP_NO_STEM_FUSE=1), one launch fewer, the same FLOPs on the counters; below the
+    kernel's two rounds of tiles (here: 8 faces) nothing is fused.  Repeated calls return the same bits."""
+    rng = np.random.default_rng(29)
+    chips = rng.integers(0, 256, size=(37, 112, 112, 3), dtype=np.uint8)
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (2, 1, 1, 1))
+    engine.load_weights(blob)
+    out = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("FRP_NO_STEM_FUSE", "1")
+        for n in (37, 8):
+            engine.reset_counters()
+            e = engine.embed_aligned(chips[:n])
+            c = engine.counters()
+            out[mode, n] = (e, c["emb_conv_launches"], c["emb_conv_flops"])
+    monkeypatch.delenv("FRP_NO_STEM_FUSE")
+    (a, la, fa), (b, lb, fb) = out["fused", 37], out["separate", 37]
+    assert la == lb - 1 and abs(fa - fb) <= 1e-6 * fb
+    assert np.array_equal(a, b)
+    assert out["fused", 8][1] == out["separate", 8][1] and np.array_equal(out["fused", 8][0], out["separate", 8][0])
+    for _ in range(5):
+        assert np.array_equal(engine.embed_aligned(chips), a)
+    ref = onet.emb_forward(raw, onet.emb_blob(chips[:4]))
+    assert (a[:4] * ref).sum(1).min() > 1 - 1e-3
 
 
 def test_stride2_row_patch_kernel_in_the_embedder_with_the_shortcut_segments(engine, monkeypatch):
