@@ -51,6 +51,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 64-channel patch in LDS (and stores the tile's own pixels of that map for the block's shortcut) - the patch of tile t + 1 in the
 // iteration that multiplies tile t, so the one barrier per tile stays and the phase is not exposed between two barriers (as a phase of
 // its own in front of the k-loop the fused launch took as long as the two launches it replaces).  Same instructions on the same operands as emb_stem_kernel and as the unfused k-loop: bit-identical.
+#ifndef C64S_ABL
+#define C64S_ABL 0                          // lab builds: timing ablations of the fused stem (1: no stem phase, 2: no stores of the stem map, 4: no patch writes, 8: no output stores)
+#endif
 #define C64_CHIP_SLOT 8192                  // chips under a patch: (TH + 4) x (TW + 4) pixels of 16 B <= 512 pixels
 #define C64_OFF_CHIPS (2 * C64_BUF)          // (the patch is double-buffered: the stem phase of tile t + 1 runs beside the k-loop of tile t)
 #define C64_OFF_SW (C64_OFF_CHIPS + 3 * C64_CHIP_SLOT)       // stem weight fragments [cout group][kh][lane] (6 KiB)
@@ -245,9 +248,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
                         swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
                         swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
                         u32x4 o = {pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]};     // couts 32 cg + 16 q + 8 fh .. + 7
+                        if (C64S_ABL & 2) asm volatile("" ::"v"(o)); else
                         __builtin_amdgcn_raw_buffer_store_b128(o, srsrc, goff + cg * 64 + q * 32, 0, 0);
                         if (!inimg) o = u32x4{0u, 0u, 0u, 0u};                  // the conv's zero padding, not the stem of padded chips
-                        if (valid) *reinterpret_cast<u32x4*>(prow + cg * 64 + q * 32) = o;
+                        if (valid && !(C64S_ABL & 4)) *reinterpret_cast<u32x4*>(prow + cg * 64 + q * 32) = o;
                     }
                 }
             }
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
         if (STEM) {
             // the chips of tile ct + 1 (consumed below) have landed once only this wave's stores behind them may be pending: 4 per patch
             // block of the stem phase that followed their issue + - from the second tile on - the last epilogue's 4
-            if (ct == t0) { if (n_myblk == 2) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
+            if (C64S_ABL) wait_vmcnt<0>();
+            else if (ct == t0) { if (n_myblk == 2) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
             else if (n_myblk == 2) wait_vmcnt<12>();
             else wait_vmcnt<8>();
         } else if (ct == t0) wait_vmcnt<6>();
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
             // the next tile's patch: waves 0-3 build their blocks BEFORE this tile's k-loop, waves 4-7 behind its epilogue - the two waves of
             // a SIMD (w and w + 4) are then in opposite phases, one converting and packing while the other multiplies (all eight in the
             // same order: +2.4 us per 5 us tile, the fused launch as long as the two it replaces)
-            if (wave < 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
+            if (!(C64S_ABL & 1) && wave < 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
         }
         // the patch two tiles ahead goes out BETWEEN the MFMAs below (its address arithmetic hides under matrix time; it has two
         // tiles to land); past the end: zero-fill into a slot nobody reads
@@ -385,10 +390,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
                 swap_halves(pk[2 * q].u[0], pk[2 * q + 1].u[0]);
                 swap_halves(pk[2 * q].u[1], pk[2 * q + 1].u[1]);
                 const u32x4 o = {pk[2 * q].u[0], pk[2 * q].u[1], pk[2 * q + 1].u[0], pk[2 * q + 1].u[1]};
+                if (STEM && (C64S_ABL & 8)) asm volatile("" ::"v"(o)); else
                 __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[b] + 32 * q, 0, 0);   // couts 32 wave_c + 16 q + 8 fh .. + 7
             }
         }
-        if (STEM && wave >= 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
+        if (STEM && !(C64S_ABL & 1) && wave >= 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
         slot = slot + 1 == C64_NBUF ? 0 : slot + 1;
     }
     // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
