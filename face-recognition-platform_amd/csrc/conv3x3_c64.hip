@@ -270,66 +270,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
     }
     constexpr bool has_res = RES;
 
-    int slot = 0, it = 0;
-    for (int ct = t0; ct < t1; ct += tstep, ++it) {
-        // tile ct has landed: behind its pieces in the in-order counter sit the next tile's six pieces and - from the second tile
-        // on - the four stores of the last epilogue (unconditional: the count is exact)
-        if (STEM) {
-            // the chips of tile ct + 1 (consumed below) have landed once only this wave's stores behind them may be pending: 4 per patch
-            // block of the stem phase that followed their issue + - from the second tile on - the last epilogue's 4
-            if (C64S_ABL) wait_vmcnt<0>();
-            else if (ct == t0) { if (n_myblk == 2) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
-            else if (n_myblk == 2) wait_vmcnt<12>();
-            else wait_vmcnt<8>();
-        } else if (ct == t0) wait_vmcnt<6>();
-        else if (has_res) wait_vmcnt<14>();    // (the epilogue's four residual loads sit in front of its stores)
-        else wait_vmcnt<10>();
-        retire_lds_reads();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" : "+v"(lane_e));
-        int nslot = slot + 2;
-        nslot = nslot >= C64_NBUF ? nslot - C64_NBUF : nslot;
-        if (STEM) {
-            issue_chips(ct + 2 * tstep, nslot);                       // into the slot the previous iteration's stem phase read
-            // the next tile's patch: waves 0-3 build their blocks BEFORE this tile's k-loop, waves 4-7 behind its epilogue - the two waves of
-            // a SIMD (w and w + 4) are then in opposite phases, one converting and packing while the other multiplies (all eight in the
-            // same order: +2.4 us per 5 us tile, the fused launch as long as the two it replaces)
-            if (!(C64S_ABL & 1) && wave < 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
-        }
-        // the patch two tiles ahead goes out BETWEEN the MFMAs below (its address arithmetic hides under matrix time; it has two
-        // tiles to land); past the end: zero-fill into a slot nobody reads
-        const Patch nq = patch_of(ct + 2 * tstep);
-
-        const int n = ct / per, r = ct - n * per;
+    // ---------------- epilogue of a tile: lane = pixel (oy0 + b, ox), registers 4g .. 4g+3 = couts 32 wave_c + 8g + 4 fh .. + 3
+    floatx16 acc[2];
+    auto epilogue = [&](int tile) __attribute__((always_inline)) {
+        const int n = tile / per, r = tile - n * per;
         const int ty = r / tx_n, tx = r - ty * tx_n;
         const int oy0 = ty * C64_TH + 2 * wave_p * C64_RB + lrow, ox = tx * C64_TW + lcol;
-        const int boff = STEM ? (it & 1) * C64_BUF : slot * C64_BUF;
-
-        floatx16 acc[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-        half8 bf[3][2];                        // fragments of k-slices s, s + 1, s + 2 (requested two slices ahead of their MFMAs)
-        const unsigned char* pb = smem + (fbase + boff);
-        auto rd = [&](int s, int S) {
-            const int tap = s >> 2, kk = s & 3;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                bf[S][b] = *reinterpret_cast<const half8*>(pb + ((b * C64_RB + tap / 3) * C64_PW + tap % 3) * C64_PITCH + kk * 32);
-        };
-        rd(0, 0);
-        rd(1, 1);
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
-            if (s + 2 < 36) rd(s + 2, (s + 2) % 3);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bf[s % 3][b], acc[b], 0, 0, 0);
-            if (!STEM && s % 5 == 4 && s / 5 < 6) issue_piece(nq, s / 5, nslot);
-            __builtin_amdgcn_sched_barrier(0);             // (the slices stay in this order: the compiler pulls the reads next to their MFMAs)
-        }
-
-        // ---------------- epilogue: lane = pixel (oy0 + b, ox), registers 4g .. 4g+3 = couts 32 wave_c + 8g + 4 fh .. + 3
         u32x4 rr[2][2];
         unsigned ooff[2];
 #pragma unroll
@@ -394,9 +340,86 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(ConvParams p_in) {
                 __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[b] + 32 * q, 0, 0);   // couts 32 wave_c + 16 q + 8 fh .. + 7
             }
         }
-        if (STEM && !(C64S_ABL & 1) && wave >= 4 && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
+    };
+
+    // PING-PONG: the two waves of a SIMD (w and w + 4) run the iteration's two halves in opposite order.  Waves 0-3 multiply tile ct, then
+    // convert and store it; waves 4-7 first convert and store tile ct - 1 (their accumulators wait across the barrier), then multiply tile
+    // ct - so one wave's 72 MFMAs run under its partner's epilogue instead of both waves sharing the matrix core and then both leaving it
+    // idle (a tile took 4.9 us with NO memory traffic at all, 2.8 of them MFMAs: profiles/r5/ab_stem_fusion.txt).  One barrier per tile as
+    // before; a wave's own operations keep their order, so the counted waits only change for the late waves' first two tiles.
+    // Measured (tools/c64_pingpong_probe.py, same process): 272 x 480 with residual 404 -> 383 us, without 344 -> 338, in the pipeline the
+    // detector -37 us per step.  The fused-stem variant does NOT take it (its late waves' accumulators next to the stem phase's registers:
+    // 13 spilled registers, embedder +35 us): there the stem phase alone is dealt to the two halves of the iteration.
+    const bool late = !STEM && wave >= 4 && !(p.dbg & 4096);   // (dbg bit 4096 = flags bit 22 of frp_conv2d_nhwc / frp_conv_bench: all waves in the same order - A/B runs)
+    const bool stem_first = STEM && wave < 4;
+    int slot = 0, it = 0;
+    for (int ct = t0; ct < t1; ct += tstep, ++it) {
+        // tile ct has landed: behind its pieces in the in-order counter sit the next tile's six pieces and - from the second tile
+        // on - the four stores of the last epilogue (unconditional: the count is exact)
+        if (STEM) {
+            // the chips of tile ct + 1 (consumed below) have landed once only this wave's stores behind them may be pending: 4 per patch
+            // block of the stem phase that followed their issue + - from the second tile on - the last epilogue's 4
+            if (C64S_ABL) wait_vmcnt<0>();
+            else if (ct == t0) { if (n_myblk == 2) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
+            else if (n_myblk == 2) wait_vmcnt<12>();
+            else wait_vmcnt<8>();
+        } else if (ct == t0 || (late && it == 1)) wait_vmcnt<6>();
+        else if (has_res) wait_vmcnt<14>();    // (the epilogue's four residual loads sit in front of its stores)
+        else wait_vmcnt<10>();
+        retire_lds_reads();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" : "+v"(lane_e));
+        int nslot = slot + 2;
+        nslot = nslot >= C64_NBUF ? nslot - C64_NBUF : nslot;
+        if (STEM) {
+            issue_chips(ct + 2 * tstep, nslot);                       // into the slot the previous iteration's stem phase read
+            // (the next tile's patch: waves 0-3 build their blocks BEFORE this tile's k-loop, waves 4-7 behind its epilogue - the two waves
+            // of a SIMD, w and w + 4, convert and pack at different times)
+        }
+        if (late && it > 0) epilogue(ct - tstep);
+        if (STEM && !(C64S_ABL & 1) && stem_first && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
+        // the patch two tiles ahead goes out BETWEEN the MFMAs below (its address arithmetic hides under matrix time; it has two
+        // tiles to land); past the end: zero-fill into a slot nobody reads
+        const Patch nq = patch_of(ct + 2 * tstep);
+
+        const int boff = STEM ? (it & 1) * C64_BUF : slot * C64_BUF;
+
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        half8 bf[3][2];                        // fragments of k-slices s, s + 1, s + 2 (requested two slices ahead of their MFMAs)
+        const unsigned char* pb = smem + (fbase + boff);
+        auto rd = [&](int s, int S) {
+            const int tap = s >> 2, kk = s & 3;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                bf[S][b] = *reinterpret_cast<const half8*>(pb + ((b * C64_RB + tap / 3) * C64_PW + tap % 3) * C64_PITCH + kk * 32);
+        };
+        rd(0, 0);
+        rd(1, 1);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 2 < 36) rd(s + 2, (s + 2) % 3);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bf[s % 3][b], acc[b], 0, 0, 0);
+            if (!STEM && s % 5 == 4 && s / 5 < 6) issue_piece(nq, s / 5, nslot);
+            __builtin_amdgcn_sched_barrier(0);             // (the slices stay in this order: the compiler pulls the reads next to their MFMAs)
+        }
+
+        if (!late) {
+            epilogue(ct);
+            // (the early waves' accumulators are dead here; said in a way the register allocator sees - it does not correlate this branch
+            // with the late waves' deferred epilogue and would keep all 32 registers live through the stem phase below)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        }
+        if (STEM && !(C64S_ABL & 1) && !stem_first && ct + tstep < t1) stem_phase(ct + tstep, slot + 1 == C64_NBUF ? 0 : slot + 1, (it + 1) & 1);
         slot = slot + 1 == C64_NBUF ? 0 : slot + 1;
     }
+    if (late) epilogue(t0 + (it - 1) * tstep);             // the late waves' last tile
     // nothing of this workgroup's DMA stream may still be in flight when its LDS is handed to the next workgroup
     wait_vmcnt<0>();
 }

@@ -2349,7 +2349,7 @@ int frp_conv2d_nhwc(frp_handle* h, const void* x, int32_t N, int32_t H, int32_t 
             p.out = dout.p;
             p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ksize; p.stride = stride; p.act = act;
             p.flags = flags & (FRP_FLAG_BORDER_BIAS | FRP_FLAG_OUT_F32 | FRP_FLAG_RES_UP2);
-            p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0);      // (bit 20: not the 64 -> 64 kernel; bit 21: the opt-in stride-2 row-patch kernel)      // kernel A/B switches (tests: 1 = generic kernel instead of the
+            p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0) | ((flags & 0x400000) ? 4096 : 0);      // (bit 20: not the 64 -> 64 kernel; bit 21: the opt-in stride-2 row-patch kernel)      // kernel A/B switches (tests: 1 = generic kernel instead of the
                                                                                 // row-patch one; flags bit 19 = dbg 256: the Winograd kernel's 2-D tiles, lab build)
             // flags bit 17 / 18: quarter tiles always / never (default: by the tile count, conv_common.h: conv_small_m)
             p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || want_wino) ? -1 : 0;
@@ -2458,7 +2458,7 @@ int frp_conv_bench(frp_handle* h, int32_t N, int32_t H, int32_t W, int32_t Cin, 
             if (!(flags & FRP_FLAG_OUT_FP8)) p.out2 = dr.p;   // conv2-style: fp16 out + fp8 copy (residual buffer doubles as the copy target when unused)
             if (with_res) p.out2 = nullptr;
         }
-        p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0);      // (bit 20: not the 64 -> 64 kernel)
+        p.dbg = ((flags >> 8) & 0xff) | ((flags & 0x80000) ? 256 : 0) | ((flags & 0x100000) ? 512 : 0) | ((flags & 0x200000) ? 2048 : 0) | ((flags & 0x400000) ? 4096 : 0);      // (bit 20: not the 64 -> 64 kernel)
         p.small_m = (flags & 0x20000) ? 1 : ((flags & 0x40000) || (flags & 0x10000)) ? -1 : 0;
         DevBuf dwino;
         bool wino_shape = conv3x3_wino_shape_ok(W, Cin, ksize, stride) || (ksize == 3 && stride == 1 && conv3x3_wino_wide_pays(N, H, W, Cin, Cout, h->n_cu, with_res != 0));
