@@ -75,6 +75,15 @@ def main():
         name = r["Kernel_Name"]
         if "conv_mfma" in name or "conv3x3_rows" in name or "conv3x3_lean" in name or "conv3x3_wino" in name or "conv3x3_c64" in name:
             l, h, w, fl, by = next(convs)
+            stem_fused = "conv3x3_c64" in name and name.rstrip().endswith(", true>(frp::ConvParams)")
+            if stem_fused:
+                # the embedder's stem runs inside this launch (conv3x3_c64.hip, STEM): FLOPs of both convs; bytes = the chips, a quarter
+                # of the stem's map (its even pixels, for the block's shortcut), the conv's output and weights
+                l2, h2, w2, fl2, by2 = next(convs)
+                n_img = by2 // (h2 * w2 * 64 * 2 * 2)
+                by = n_img * h * w * 8 * 2 + n_img * h * w * 64 * 2 // 4 + n_img * h2 * w2 * 64 * 2 + (64 * 64 * 9 + 64 * 8 * 9) * 2
+                fl += fl2
+                l, h, w = l2, h2, w2
             cfg = re.search(r"<(\d+), (\d+),", name)
             wino = "conv3x3_wino" in name
             c64 = "conv3x3_c64" in name
@@ -84,7 +93,7 @@ def main():
             bounds.append((d, bound))
             print(f"{l.name:28s} {h:4d}x{w:<4d} {l.cin:5d}->{l.cout:3d} k{l.k}s{l.stride} grid {r['Grid_Size_X']:>7s} "
                   f"{d:8.1f} us  gap {gap:6.1f}  {fl / d / 1e6:7.1f} TF  {by / d / 1e3:7.1f} GB/s  x{d / bound:4.2f} of "
-                  f"{'mfma' if fl / 1.25e9 >= by / 4.5e6 else 'hbm '} bound  " + (("winograd F(2,3), 8x30-pixel tiles x 128" if "wino2_kernel<32>" in name else "winograd F(2,3) 256x128") if wino else ((f"64 -> 64 kernel, {'16x16' if name.rstrip().endswith(', 16>(frp::ConvParams)') else '32x8'}-pixel tiles, weights in registers") if c64 else f"tile {cfg.group(1)}x{cfg.group(2)}")))
+                  f"{'mfma' if fl / 1.25e9 >= by / 4.5e6 else 'hbm '} bound  " + (("winograd F(2,3), 8x30-pixel tiles x 128" if "wino2_kernel<32>" in name else "winograd F(2,3) 256x128") if wino else ((f"64 -> 64 kernel, {'16x16' if ', 16, ' in name else '32x8'}-pixel tiles, weights in registers" + (", the stem conv in the same launch" if stem_fused else "")) if c64 else f"tile {cfg.group(1)}x{cfg.group(2)}")))
         else:
             print(f"{name[:57]:57s} grid {r['Grid_Size_X']:>9s} {d:8.1f} us  gap {gap:6.1f}")
     print(f"sum of kernels {tot:.1f} us, sum of gaps {tot_gap:.1f} us, span {(prev_end - t0) / 1e3:.1f} us")
