@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 import frp_amd_loader  # noqa: E402,F401
 from frp_amd import native, netspec, weights  # noqa: E402
 
-LANE_SETTLE_STEPS = 20      # untimed two-lane steps in front of the timed region (see run_steps' caller)
+LANE_SETTLE_STEPS = int(os.environ.get("FRP_BENCH_SETTLE", "20"))      # untimed two-lane steps in front of the timed region (see run_steps' caller)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 

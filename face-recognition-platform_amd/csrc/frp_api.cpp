@@ -428,7 +428,9 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
                 const frp_conv_op& b = net.ops[nb];
                 const bool plain = !(b.flags & ~FRP_FLAG_BORDER_BIAS) && (b.flags & FRP_FLAG_BORDER_BIAS) && b.out2_buf < 0 && b.res_buf < 0;
                 const bool chained = !(nb < net.kc_src.size() && net.kc_src[nb] >= 0);
-                fuse_stem = plain && chained && b.in_buf == a.out_buf && b.out_buf != a.out_buf && b.cin == 64 && b.cout == 64 && b.ksize == 3 &&
+                // (the fused launch reads the chips while it writes both maps: none of the three buffers may be another's alias - this
+                // packer pins network inputs, a foreign blob's plan might not)
+                fuse_stem = plain && chained && b.in_buf == a.out_buf && b.out_buf != a.out_buf && b.out_buf != a.in_buf && a.out_buf != a.in_buf && b.cin == 64 && b.cout == 64 && b.ksize == 3 &&
                             b.stride == 1 && b.act == FRP_ACT_PRELU && b.slope_off >= 0 && conv3x3_c64_fuses_stem(batch, H, W, h->n_cu);
                 fuse_op = nb;
                 // who else reads the stem's map?  Only shortcut convs (1x1, stride 2) that ride in a later k-loop: then a quarter of its
