@@ -54,6 +54,20 @@ struct Net {
 
 enum { EV_START = 0, EV_H2D, EV_PRE, EV_DET, EV_DEC, EV_ALIGN, EV_EMB, EV_L2, EV_MATCH, EV_D2H, EV_COUNT };
 
+// A network pass as a captured hipGraph (round 5): the ~50 / ~85 launches of a detector / embedder pass replayed by ONE call when the
+// same pass - same program, shapes, buffers, operands, switches - is asked for again (run_net).  What the host side of the pass does
+// besides launching (counters, the FC's split-K bookkeeping, the planned dims) is recorded with it and re-applied on replay.
+struct NetGraph {
+    std::string key;
+    hipGraphExec_t exec = nullptr;
+    uint64_t epoch = 0;                 // frp_handle::alloc_epoch at capture: any (re)allocation or weight load since makes it stale
+    double dflops = 0, df8flops = 0;
+    int64_t dlaunches = 0, df8launches = 0;
+    int fc_ksplit = 0, fc_ktot = 0;
+    const float* fc_bias = nullptr;
+    std::vector<TensorDims> dims;
+};
+
 }  // namespace
 
 struct frp_handle {
@@ -84,6 +98,12 @@ struct frp_handle {
     bool det_scaled = false;
     int canvas_h = 0, canvas_w = 0;
     int det_op_limit = -1;           // >= 0: frp_debug_det_prefix - the detector program stops behind this many ops
+    // captured passes (run_net): graphs, the keys seen once (a pass is captured the SECOND time it is asked for: the first allocates and
+    // sets kernel attributes), the keys whose capture failed, the allocation epoch
+    std::vector<NetGraph> graphs;
+    std::vector<std::string> graph_seen, graph_bad;
+    uint64_t alloc_epoch = 1;
+    int64_t graph_replays = 0;
     // multi-GPU (frp_dist_init): this handle's RCCL communicator, rank and world size
     void* comm = nullptr;
     int dist_rank = 0, dist_world = 0;
@@ -183,6 +203,7 @@ int ensure(frp_handle* h, DevBuf& b, size_t bytes) {
         b.cap = 0;
     }
     const size_t want = std::max<size_t>(bytes, 256);
+    ++h->alloc_epoch;                   // (captured passes hold device pointers)
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         b.p = nullptr;
@@ -362,8 +383,8 @@ bool stem12_fusable(const Net& net) {
 // planned for): every kernel derives its tile count from it.  The flop counters are charged for `batch` images and
 // corrected by the caller once the count is known.
 // `allow_wino` false: the direct kernels also where a Winograd weight image exists (calls of few faces, run_embed).
-int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr,
-            const int32_t* n_dev = nullptr, bool allow_wino = true) {
+int run_net_body(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem,
+                 const int32_t* n_dev, bool allow_wino) {
     // dims are re-derived while walking (physical buffers are reused by several tensors)
     std::vector<TensorDims> d(net.n_bufs);
     d[net.in_buf] = {H, W, net.in_ch, false};
@@ -589,6 +610,97 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
         *launches += 1;
     }
     net.dims = d;
+    return FRP_OK;
+}
+
+static void drop_graphs(frp_handle* h) {
+    for (NetGraph& g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->graph_seen.clear();
+    h->graph_bad.clear();
+}
+
+// The pass, replayed from its captured graph when it has been asked for before (FRP_NO_GRAPH=1: always launch by launch).  The key names
+// everything the launches depend on that is not fixed by the loaded weights: program, shapes, family, operand pointers, every switch
+// run_net_body reads; device buffers and weights are covered by the allocation epoch.  Not with stage timers (events between the
+// passes are fine, but the diagnostics inside a pass are not captured), not with the detector diagnostics.
+int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int64_t* launches, const StemParams* stem = nullptr,
+            const int32_t* n_dev = nullptr, bool allow_wino = true) {
+    static const bool off = getenv("FRP_NO_GRAPH") != nullptr;
+    if (off || h->det_hash_on || h->det_op_limit >= 0) return run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    char kb[512];
+    auto env = [](const char* n) { const char* v = getenv(n); return v ? (v[0] ? v[0] : '1') : '-'; };
+    int len = snprintf(kb, sizeof kb, "%c|%d|%d|%d|%d|%p|%p|%c%c%c%c%c%c%c%c|", &net == &h->det ? 'd' : 'e', batch, H, W, (int)allow_wino, (const void*)n_dev,
+                       (const void*)h->wdata.p, env("FRP_SMALL_M"), env("FRP_S2"), env("FRP_NO_STEM_FUSE"), env("FRP_STEM_FULL_MAP"),
+                       env("FRP_NO_FUSED_STEM12"), env("FRP_NO_EMB_STEM"), env("FRP_NO_SPLITK"), env("FRP_NO_PREFETCH"));
+    if (stem && len > 0 && len < (int)sizeof kb)
+        len += snprintf(kb + len, sizeof kb - len, "%p|%d|%d|%d|%ld|%ld|%d|%d|%d", (const void*)stem->frames, stem->B, stem->H, stem->W, stem->row_stride,
+                        stem->frame_stride, stem->Hc, stem->Wc, stem->rgb_in);
+    if (len <= 0 || len >= (int)sizeof kb) return run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    const std::string key(kb);
+    for (size_t i = 0; i < h->graphs.size(); ++i) {
+        NetGraph& g = h->graphs[i];
+        if (g.key != key) continue;
+        if (g.epoch != h->alloc_epoch) {            // its buffers may have moved
+            (void)hipGraphExecDestroy(g.exec);
+            h->graphs.erase(h->graphs.begin() + i);
+            break;
+        }
+        HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
+        *flops += g.dflops;
+        *launches += g.dlaunches;
+        h->ctr.f8_conv_flops += g.df8flops;
+        h->ctr.f8_conv_launches += g.df8launches;
+        h->fc_ksplit = g.fc_ksplit; h->fc_bias = g.fc_bias; h->fc_ktot = g.fc_ktot;
+        net.dims = g.dims;
+        h->graph_replays += 1;
+        return FRP_OK;
+    }
+    auto has = [](const std::vector<std::string>& v, const std::string& k) { for (const std::string& x : v) if (x == k) return true; return false; };
+    if (has(h->graph_bad, key) || !has(h->graph_seen, key)) {
+        if (h->graph_seen.size() > 256) h->graph_seen.clear();
+        if (!has(h->graph_seen, key)) h->graph_seen.push_back(key);
+        return run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    }
+    // second request for this pass: capture it (thread-local mode: the other lanes' threads keep allocating and synchronising as they like)
+    const uint64_t epoch0 = h->alloc_epoch;
+    const double f0 = *flops, f80 = h->ctr.f8_conv_flops;
+    const int64_t l0 = *launches, l80 = h->ctr.f8_conv_launches;
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        h->graph_bad.push_back(key);
+        return run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    }
+    const int rc = run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    NetGraph g;
+    bool ok = rc == FRP_OK && ce == hipSuccess && graph && h->alloc_epoch == epoch0;
+    if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+        // nothing of the captured pass has run: say so once, then do it launch by launch (the counters were charged by the capture pass)
+        (void)hipGetLastError();
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graph_bad.push_back(key);
+        if (rc != FRP_OK) return rc;
+        *flops = f0; *launches = l0; h->ctr.f8_conv_flops = f80; h->ctr.f8_conv_launches = l80;
+        return run_net_body(h, net, batch, H, W, flops, launches, stem, n_dev, allow_wino);
+    }
+    g.key = key;
+    g.epoch = epoch0;
+    g.dflops = *flops - f0; g.dlaunches = *launches - l0;
+    g.df8flops = h->ctr.f8_conv_flops - f80; g.df8launches = h->ctr.f8_conv_launches - l80;
+    g.fc_ksplit = h->fc_ksplit; g.fc_bias = h->fc_bias; g.fc_ktot = h->fc_ktot;
+    g.dims = net.dims;
+    if (h->graphs.size() >= 16) {                  // (two frame buffers x two networks x a few call shapes; the oldest goes)
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+    }
+    const hipError_t le = hipGraphLaunch(g.exec, h->stream);
+    h->graphs.push_back(g);
+    if (le != hipSuccess) return fail(h, FRP_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
     return FRP_OK;
 }
 
@@ -1140,6 +1252,7 @@ void frp_destroy(frp_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->comm) { (void)rccl().CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
+    drop_graphs(h);
     for (DevBuf& b : h->det.bufs) release(b);
     for (DevBuf& b : h->emb.bufs) release(b);
     DevBuf* all[] = {&h->wdata, &h->frames, &h->frames_next, &h->boxes, &h->kps, &h->scores, &h->counts, &h->anchor, &h->face_slot, &h->nfaces,
@@ -1167,6 +1280,7 @@ int frp_load_weights(frp_handle* h, const void* blob, size_t bytes) {
     if (!h) return FRP_ERR_INVALID;
     Guard g(h);
     h->have_weights = false;          // a failed load never leaves a half-replaced program runnable
+    ++h->alloc_epoch;                 // (captured passes of the old program are stale even where the new one lands in the same allocation)
     if (!blob || bytes < sizeof(frp_blob_header)) return fail(h, FRP_ERR_BLOB, "blob too small");
     frp_blob_header hd;
     memcpy(&hd, blob, sizeof(hd));
@@ -1892,6 +2006,12 @@ int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size
 }
 
 // diagnostic: how many frp_upload_jpeg_async batches had their entropy decode on the device (restart-interval streams)
+int64_t frp_debug_graph_replays(frp_handle* h) {
+    if (!h) return -1;
+    Guard g(h);
+    return h->graph_replays;
+}
+
 int64_t frp_debug_jpeg_device_batches(frp_handle* h) {
     if (!h) return -1;
     Guard g(h, false);

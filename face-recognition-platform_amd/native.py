@@ -30,7 +30,7 @@ F32, F16, F64 = 0, 1, 2
 ABI_SYMBOLS = [
     "frp_create", "frp_destroy", "frp_last_error", "frp_version", "frp_load_weights",
     "frp_gallery_set", "frp_gallery_set_device", "frp_gallery_reserve", "frp_gallery_commit", "frp_gallery_cancel", "frp_gallery_device_ptr", "frp_gallery_update_row", "frp_gallery_remove_row",
-    "frp_jpeg_info_get", "frp_jpeg_coefficients", "frp_upload_jpeg_async", "frp_debug_jpeg_device_batches",
+    "frp_jpeg_info_get", "frp_jpeg_coefficients", "frp_upload_jpeg_async", "frp_debug_jpeg_device_batches", "frp_debug_graph_replays",
     "frp_dist_unique_id", "frp_dist_init", "frp_dist_destroy", "frp_gallery_allgather",
     "frp_gallery_size", "frp_gallery_get", "frp_gallery_exact", "frp_gallery_distances", "frp_gallery_get_exact",
     "frp_process_frames", "frp_upload_frames", "frp_process_resident", "frp_fetch_results", "frp_synchronize",
@@ -185,6 +185,8 @@ def load_library() -> C.CDLL:
     lib.frp_get_head_map.argtypes = [vp, i32, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.frp_debug_jpeg_device_batches.argtypes = [vp]
     lib.frp_debug_jpeg_device_batches.restype = C.c_int64
+    lib.frp_debug_graph_replays.argtypes = [vp]
+    lib.frp_debug_graph_replays.restype = C.c_int64
     lib.frp_dist_unique_id.argtypes = [vp]
     lib.frp_dist_init.argtypes = [vp, vp, i32, i32]
     lib.frp_dist_destroy.argtypes = [vp]
@@ -354,6 +356,10 @@ class Engine:
     def jpeg_device_batches(self) -> int:
         """diagnostic: upload_jpeg_async batches whose entropy decode ran on the device (restart-interval streams)"""
         return int(self._lib.frp_debug_jpeg_device_batches(self._h))
+
+    def graph_replays(self) -> int:
+        """diagnostic: detector / embedder passes replayed from a captured hipGraph so far (frp.h: frp_debug_graph_replays)"""
+        return int(self._lib.frp_debug_graph_replays(self._h))
 
     def gallery_exact(self, on: bool = True):
         """keep every row also as float64, as enrolled (frp.h: frp_gallery_exact): the rows behind gallery_distances"""

@@ -207,6 +207,9 @@ int frp_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* coef, size_
 int frp_upload_jpeg_async(frp_handle* h, const uint8_t* const* jpegs, const size_t* sizes, int32_t B);
 /* diagnostic: batches of this handle whose ENTROPY decode ran on the device too (every frame carries restart intervals of at most 32
  * MCUs - one thread per interval; longer intervals: the host decoder, unless FRP_JPEG_DEVICE_HUFFMAN=1; =0: always the host) */
+/* network passes replayed from a captured hipGraph so far (round 5: a detector / embedder pass asked for a second time with the same shapes,
+ * buffers and switches is captured and from then on replayed by one call; FRP_NO_GRAPH=1 turns that off) - tests and diagnosis */
+int64_t frp_debug_graph_replays(frp_handle* h);
 int64_t frp_debug_jpeg_device_batches(frp_handle* h);
 
 /* ---- multi-GPU: one process per GPU, ONE collective ----------------------------------------------------

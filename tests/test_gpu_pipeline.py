@@ -503,6 +503,63 @@ def test_headline_step_is_bit_reproducible(fresh_engine):
         engine.det_hashes(False, fetch=False)
 
 
+def test_network_passes_replayed_from_captured_graphs_give_the_same_bits_and_counters(fresh_engine):
+    """A detector / embedder pass asked for a second time with the same shapes, buffers and switches is captured as a hipGraph and from
+    then on replayed by one call (frp_api.cpp: run_net).  Forced-K and threshold mode (device-side face count): the first call (launch
+    by launch), the capturing call and four replays return the same bits and charge the same counters; replays are counted; a weight
+    reload and a changed batch size retire the stale graphs (results then equal a fresh handle's first, uncaptured call)."""
+    from frp_amd import native
+    engine = fresh_engine
+    raw, blob = get_raw_and_blob((1, 1, 1, 1), (1, 1, 1, 1))
+    raw2, blob2 = get_raw_and_blob((1, 2, 2, 2), (1, 1, 1, 1))
+    rng = np.random.default_rng(41)
+    B, H, W, K = 6, 720, 1280, 5
+    frames = _frames(rng, B, H, W)
+    G = rng.standard_normal((3000, 512)).astype(np.float32)
+    keys = ("boxes", "kps", "scores", "counts", "emb", "match_idx", "match_cos")
+    ckeys = ("det_conv_flops", "det_conv_launches", "emb_conv_flops", "emb_conv_launches", "faces", "frames")
+
+    def run(e, flags, thresh, n=B):
+        e.reset_counters()
+        e.process_resident(K, det_thresh=thresh, flags=flags)
+        r = e.fetch_results()
+        c = e.counters()
+        return r, {k: c[k] for k in ckeys}
+
+    engine.load_weights(blob)
+    engine.gallery_set(G)
+    engine.upload_frames(frames)
+    probe = engine.detect_resident((H, W), max_faces=64, det_thresh=1e-6, nms_iou=0.4)
+    thr = float(np.clip(np.median(np.sort(probe["scores"], axis=1)[:, ::-1][:, 2]), 1e-4, 0.9999))      # ~3 faces per frame survive
+    for flags, thresh in ((native.FLAG_FORCED_K, 0.5), (0, thr)):
+        replays0 = engine.graph_replays()
+        first, c_first = run(engine, flags, thresh)
+        for i in range(5):
+            got, c_got = run(engine, flags, thresh)
+            for k in keys:
+                assert np.array_equal(first[k], got[k]), f"call {i + 2} (flags {flags}): {k} differs from the first call"
+            assert c_got == c_first, f"call {i + 2}: counters {c_got} != {c_first}"
+        assert engine.graph_replays() - replays0 >= 2 * 4          # detector + embedder pass of calls 3 .. 6
+        if not flags:
+            assert 0 < first["counts"].sum() < B * K
+    # stale graphs: another program in the same allocation, then another batch size - against a handle that has never captured anything
+    other = native.Engine(0)
+    try:
+        other.load_weights(blob2)
+        other.gallery_set(G)
+        engine.load_weights(blob2)
+        for n in (B, 3, B):
+            engine.upload_frames(frames[:n])
+            other.upload_frames(frames[:n])
+            want, _ = run(other, native.FLAG_FORCED_K, 0.5)
+            for _ in range(3):
+                got, _ = run(engine, native.FLAG_FORCED_K, 0.5)
+                for k in keys:
+                    assert np.array_equal(want[k], got[k]), f"{n} frames after the reload: {k} differs from a fresh handle's"
+    finally:
+        other.close()
+
+
 def test_other_config_shapes_4k_720p_and_million_gallery(engine):
     """Shapes of BASELINE configs 4 and 5 through the same path: one 3840x2160 frame (340,320 anchors,
     canvas 2176 rows), a mixed batch of 1280x720 frames, and a 1M-identity gallery (1.02 GB fp16)."""
