@@ -314,8 +314,10 @@ def main():
     ap.add_argument("--weights", default="fp16", choices=["fp16", "fp8-mfma"],
                     help="fp8-mfma: the embedder's stage 2-4 3x3 convs run on E4M3 activations and weights (BASELINE config 5)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults = the driver's own command: a timed region pays ~6 ms for starting from a drained GPU - the first pair of two-lane steps
+    # takes 26-29 ms instead of 22.5, FRP_BENCH_TRACE=1 shows it -, which is 6 % of a 10-step region and 3 % of a 20-step one)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--faces", type=int, default=10)
     ap.add_argument("--gallery", type=int, default=100000)
@@ -486,14 +488,21 @@ def main():
         if lane_errors:
             raise lane_errors[0]
 
+    step_trace = [] if os.environ.get("FRP_BENCH_TRACE") else None      # (lane, step taken, submitted, fetched) in seconds, to stderr
+
     def lane_loop(i, counter, n_steps):
         while True:
             with counter["lock"]:
                 if counter["next"] >= n_steps:
                     return
+                mine = counter["next"]
                 counter["next"] += 1
+            ta = time.perf_counter()
             lanes[i].process_resident(K, flags=flags)
+            tb = time.perf_counter()
             last[i] = lanes[i].fetch_results()
+            if step_trace is not None:
+                step_trace.append((i, mine, ta, tb, time.perf_counter()))
 
     def run_steps(n_steps):
         counter = {"next": 0, "lock": threading.Lock()}
@@ -509,10 +518,22 @@ def main():
         # figures) - `value` is a steady-state rate, so the region starts when the state is steady.  Reported as config.lane_warmup_steps.
         run_steps(max(args.warmup, LANE_SETTLE_STEPS))
     barrier()
+    import gc
+    gc_was = gc.isenabled()
+    if not os.environ.get("FRP_BENCH_GC"):          # (as timeit does: a collection of the interpreter's heap inside a 0.2 s region is not the pipeline's time)
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
+    if step_trace is not None:
+        for (i_, m_, ta_, tb_, tc_) in sorted(step_trace, key=lambda r_: r_[2]):
+            if ta_ >= t0:
+                print(f"trace lane {i_} step {m_:3d}: taken +{(ta_ - t0) * 1e3:8.2f} ms, submitted after {(tb_ - ta_) * 1e3:6.2f}, results after {(tc_ - ta_) * 1e3:7.2f}", file=sys.stderr)
+        print(f"trace region {dt * 1e3:.2f} ms", file=sys.stderr)
     per_rank = None
     if dist is not None:
         import torch

@@ -647,7 +647,13 @@ int run_net(frp_handle* h, Net& net, int batch, int H, int W, double* flops, int
             h->graphs.erase(h->graphs.begin() + i);
             break;
         }
-        HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
+        if (hipGraphLaunch(g.exec, h->stream) != hipSuccess) {      // (never seen; if the runtime refuses a replay, the pass is launched instead)
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(g.exec);
+            h->graphs.erase(h->graphs.begin() + i);
+            h->graph_bad.push_back(key);
+            break;
+        }
         *flops += g.dflops;
         *launches += g.dlaunches;
         h->ctr.f8_conv_flops += g.df8flops;
