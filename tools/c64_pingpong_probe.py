@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The 64 -> 64 kernel with and without its ping-pong (flags bit 22 = all eight waves in the same order), six alternating rounds per shape
+in one process, microseconds per launch (lab build).   python tools/c64_pingpong_probe.py"""
 import os, sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
 import _lab, frp_amd_loader
